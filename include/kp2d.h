@@ -1,0 +1,128 @@
+/* kp2d.h — C ABI of the MI355X-native kp2dtiny multi-task inference path.
+ *
+ * The reference (ETH-PBL/Nano-VS-SLAM) is pure Python: its boundary for this path is the
+ * torch.nn.Module surface of KP2DTinyV2 / KP2DTinyV3 (src/kp2dtiny/models/kp2dtiny.py:284-1015).
+ * This header is the layer UNDER that surface: the entry points a maintainer binds (ctypes stub in
+ * INTEGRATION.md) so that Module.forward / Module.post_processing and the callers' keypoint
+ * selectors run as hand-written gfx950 kernels.  Each function names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every tensor is a raw pointer + sizes; float32 unless stated
+ *   - "dev" pointers are HIP device pointers on the model's device, "host" pointers are CPU memory
+ *   - API tensors are NCHW exactly as the reference returns them
+ *   - every call returns 0 (KP2D_OK) or a negative kp2d_status; kp2d_last_error() gives the text
+ *   - all device work is enqueued on the caller's stream; no call synchronises the device except
+ *     kp2d_finalize_weights / kp2d_import_packed (one-time uploads) and kp2d_profile_* readers
+ *   - the library never allocates caller-visible memory: outputs and the workspace are caller-owned
+ *   - one handle per (device, stream); a handle is not thread-safe
+ */
+#ifndef KP2D_H_
+#define KP2D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KP2D_ABI_VERSION 1
+
+typedef enum kp2d_status {
+  KP2D_OK = 0,
+  KP2D_ERR_ARG = -1,          /* bad argument (null pointer, bad shape, H/W not divisible by 8 ...)      */
+  KP2D_ERR_UNSUPPORTED = -2,  /* configuration outside the built path (see DESIGN.md "out of scope")     */
+  KP2D_ERR_STATE = -3,        /* call order: weights not finalised, profiling off, ...                    */
+  KP2D_ERR_WEIGHT = -4,       /* unknown key / wrong shape / missing tensor at finalise                    */
+  KP2D_ERR_WORKSPACE = -5,    /* workspace too small or misaligned                                         */
+  KP2D_ERR_HIP = -6           /* a HIP runtime call or kernel launch failed                                */
+} kp2d_status;
+
+typedef struct kp2d_model kp2d_model; /* opaque */
+
+/* Constructor arguments of KP2DTinyV2.__init__ (kp2dtiny.py:301-319) / KP2DTinyV3.__init__ (:680-702)
+ * that change the arithmetic.  get_config()/tiny_factory() (:221-281) live in the Python host layer. */
+typedef struct kp2d_config {
+  int32_t struct_size;      /* sizeof(kp2d_config), for ABI evolution                                   */
+  int32_t version;          /* 2 = KP2DTinyV2, 3 = KP2DTinyV3                                            */
+  int32_t channel_dims[6];  /* c1,c2,c3,c4,c5,d1                                                         */
+  int32_t nfeatures;        /* descriptor channels                                                       */
+  int32_t n_classes;        /* nClasses                                                                  */
+  int32_t num_clusters;     /* NetVLAD K                                                                 */
+  int32_t encoder_dim;      /* NetVLAD C                                                                 */
+  int32_t downsample;       /* 2 for every S/N config (cell = 4)                                         */
+  int32_t use_attention;    /* SegFormerAttentionModule x2 in the seg head                               */
+  int32_t leaky_relu;       /* 1: LeakyReLU(0.01), 0: ReLU                                               */
+  int32_t remove_softmax;   /* V3 only (kp2dtiny.py:698,942)                                             */
+  int32_t device;           /* HIP device ordinal                                                        */
+} kp2d_config;
+
+/* kp2d_forward flags */
+#define KP2D_FWD_EVAL 1u    /* model.training is False: V3 applies Softmax2d to seg (kp2dtiny.py:942-943) */
+
+const char* kp2d_last_error(void);
+int32_t kp2d_abi_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* replaces: KP2DTinyV2(**conf, nClasses=..) / KP2DTinyV3(..) construction (eval_multitask.py:150-159) */
+int kp2d_create(const kp2d_config* cfg, kp2d_model** out);
+void kp2d_destroy(kp2d_model* m);
+
+/* ---- weights: the state_dict is the wire format ---------------------------- */
+/* enumerate the tensors the model expects, in the reference's registration order */
+int kp2d_num_weights(const kp2d_model* m);
+int kp2d_weight_info(const kp2d_model* m, int index, const char** key, int64_t shape[4], int* ndim);
+/* replaces: model.load_state_dict(sd) (eval_multitask.py:161-167, demo.py:12-15); host float32, C-contiguous.
+ * BatchNorm num_batches_tracked entries are not part of the arithmetic and are ignored if passed. */
+int kp2d_set_weight(kp2d_model* m, const char* key, const float* host, const int64_t* shape, int ndim);
+/* fold BatchNorm into per-channel scale/shift, re-lay conv weights for the kernels, upload.  Blocking. */
+int kp2d_finalize_weights(kp2d_model* m);
+/* the packed device blob, for the one-off RCCL broadcast rank 0 -> all ranks */
+size_t kp2d_packed_bytes(const kp2d_model* m);
+int kp2d_export_packed(const kp2d_model* m, void* dev_dst, void* stream);
+int kp2d_import_packed(kp2d_model* m, const void* dev_src, void* stream);
+
+/* ---- forward --------------------------------------------------------------------------------- */
+/* scratch the caller must provide for a (B,H,W) call; 256-byte aligned device memory */
+size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W);
+/* replaces: KP2DTinyV2.forward (kp2dtiny.py:552-591) / KP2DTinyV3.forward (:906-957).
+ *   x      [B,3,H,W]  RGB in [-1,1]; H, W divisible by 8
+ *   score  [B,1,H/4,W/4]  sigmoid, un-bordered      shift [B,2,H/4,W/4]  tanh ("coord" key of forward)
+ *   feat   [B,nfeatures,H/2,W/2] dense descriptors   seg   [B,n_classes,H/2,W/2] logits (V3 eval: probabilities)
+ *   vlad   [B,num_clusters*encoder_dim] */
+int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
+                 float* feat, float* seg, float* vlad, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces: post_processing (kp2dtiny.py:593-625 / :959-993).  `desc` and `seg_ids` may be NULL when the
+ * module is in training mode (the reference skips sampling: kp2dtiny.py:615).
+ *   score_out [B,1,Hc,Wc] border-zeroed   coord [B,2,Hc,Wc] pixels (ch0 = x)
+ *   desc [B,C,Hc,Wc] bilinearly sampled, unit norm   seg_ids [B,1,Hs,Ws] int64 argmax over seg's channels */
+int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,
+              int H, int W, int Hc, int Wc, int feat_c, int Hf, int Wf, int seg_c, int Hs, int Ws, float* score_out,
+              float* coord, float* desc, int64_t* seg_ids, void* stream);
+
+/* replaces the callers' selectors: threshold + top-k on the cell grid, batched and on device
+ * (evaluation/visual_odometry.py:105-117 K1, evaluation/descriptor.py:12-36 K2,
+ *  gluefactory/models/extractors/kp2dtiny.py:38-42 K3).  Order: score descending, flat index ascending.
+ *   score [B,n]; idx [B,k] (-1 padded); val [B,k] or NULL; count [B]; thr = -INFINITY for plain top-k; k <= 4096 */
+int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t* idx, float* val, int32_t* count,
+                     void* stream);
+/* gather the selected cells: pts [B,k,2] (x,y), dsel [B,k,C]; rows of padded (-1) entries are zero */
+int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
+                          float* pts, float* dsel, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* when on, every kernel launch of kp2d_forward is bracketed by HIP events on the caller's stream */
+int kp2d_set_profiling(kp2d_model* m, int on);
+/* number of launches recorded by the last kp2d_forward; blocks until those events have completed */
+int kp2d_profile_count(kp2d_model* m);
+/* one record: layer name, kernel family, elapsed ms, algorithmic FLOPs and HBM bytes of that launch */
+int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** kernel, float* ms, double* flops,
+                     double* bytes);
+/* frames per internal sub-batch (0 = automatic).  Intermediates of one sub-batch stay in the 256 MB Infinity Cache. */
+int kp2d_set_chunk_frames(kp2d_model* m, int frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KP2D_H_ */

@@ -1,0 +1,57 @@
+"""Build libkp2d_hip.so (gfx950) in-tree with hipcc.  No cmake, no JIT cache.
+
+    python3 nano-vs-slam_amd/csrc/build.py [--force]
+
+The shared object sits next to the sources so it travels with the repo snapshot to the GPU box
+(it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["conv3x3.hip", "netvlad.hip", "post.hip", "attention.hip", "kp2d_api.cpp"]
+HEADERS = ["kp2d_kernels.h", os.path.join("..", "..", "include", "kp2d.h")]
+LIB = os.path.join(HERE, "libkp2d_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src + ".o")
+        path = os.path.join(HERE, src)
+        if force or _stale(obj, [path] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=HERE)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

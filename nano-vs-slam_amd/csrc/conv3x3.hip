@@ -1,0 +1,334 @@
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the gfx950 matrix cores, exact fp32.
+//
+// Replaces every Conv2d(k=3) + BatchNorm2d(eval) + LeakyReLU stack of the reference
+// (AnnotatedConvBnReLUModel, modules/base.py:14-46) and the plain biased 3x3 convs of the heads
+// (modules/decoders/heads.py:22,72-85; modules/decoders/segmentation.py:108,277-282), with
+// MaxPool2d(2,2) (encoders.py:100), PixelShuffle(2) (heads.py:54) and torch.cat (heads.py:99)
+// folded into the load / store side instead of being separate passes over HBM.
+//
+// Mapping (one 256-thread workgroup = 4 waves):
+//   * GEMM view: M = output pixels, N = output channels (padded to 32), K = 9 taps x Cin.
+//   * Workgroup tile: 16 x 16 output pixels x all N.  Wave w owns rows 4w..4w+3 as two M-tiles of
+//     2 rows x 16 cols; inside an M-tile the MFMA row index m maps to the pixel
+//     (row = (m>>1)&1, col = 2*(m>>2) + (m&1)), so the four accumulator registers r..r+3 of a lane
+//     are one 2x2 pixel block: max-pooling is a register-local max, no LDS, no second kernel.
+//   * K is walked in chunks of KC input channels.  Per chunk the 18x18 halo tile of the (possibly
+//     concatenated) NHWC input and the [9][N][KC] weight slab are staged into LDS with 16-byte
+//     loads; both LDS images are [row][KC+4] so every MFMA operand fetch is one ds_read_b128 and
+//     the 2x16 M-tile with a 24-pixel row pitch is bank-conflict free (pitch == 8 mod 16 pixels,
+//     pixel stride 20 or 12 floats: see DESIGN.md "LDS images").
+//   * v_mfma_f32_32x32x2_f32: lane (i = lane&31, h = lane>>5) supplies A[i][k=h], B[k=h][i]; the
+//     lane's KC/2 channels are [h*KC/2, (h+1)*KC/2) so one b128 read feeds 4 MFMAs.
+//   * Epilogue on the fp32 accumulator in the reference's order: per-channel affine (BatchNorm
+//     scale/shift or bias), activation, then the store mode (NHWC / pooled / both / pixel-shuffled /
+//     planar NCHW through an LDS transpose for the API-facing tensors).
+#include "kp2d_kernels.h"
+
+namespace kp2d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = 16;
+constexpr int IN_ROWS = 18;
+constexpr int IN_PITCH = 24;
+
+__device__ __forceinline__ float act_apply(float v, int act, int ch) {
+  switch (act) {
+    case ACT_LEAKY: return v >= 0.f ? v : v * 0.01f;
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID0_TANH: return ch == 0 ? 1.f / (1.f + expf(-v)) : tanhf(v);
+    default: return v;
+  }
+}
+
+template <int KC, int NT>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KCP = KC + 4;
+  constexpr int N = NT * 32;
+  constexpr int Q = KC / 4;
+  constexpr int KH = KC / 2;
+  float* s_in = smem;
+  float* s_w = smem + IN_ROWS * IN_PITCH * KCP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * TILE, x0 = tx * TILE;
+  const int H = a.H, W = a.W;
+  const int n0 = blockIdx.y * N;   // output-channel group handled by this workgroup
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int prow = wave * 4 + ((i >> 1) & 1);
+  const int pcol = 2 * (i >> 2) + (i & 1);
+  const int a_base = (prow * IN_PITCH + pcol) * KCP + h * KH;
+  const int b_base = i * KCP + h * KH;
+
+  const int nchunk = (a.cin + KC - 1) / KC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();
+    for (int g = tid; g < IN_ROWS * IN_ROWS * Q; g += 256) {
+      const int p = g / Q, q = g - p * Q;
+      const int py = p / IN_ROWS, px = p - py * IN_ROWS;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const int c = ch * KC + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin) {
+        const size_t pix = ((size_t)b * H + gy) * W + gx;
+        const float* src = (c < a.c0) ? a.in0 + pix * a.s0 + a.o0 + c : a.in1 + pix * a.s1 + a.o1 + (c - a.c0);
+        v = *reinterpret_cast<const float4*>(src);
+      }
+      *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
+    }
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * 9 * N * KC);
+    for (int g = tid; g < 9 * N * Q; g += 256) {
+      const int row = g / Q, q = g - row * Q;
+      *reinterpret_cast<float4*>(&s_w[row * KCP + 4 * q]) = wsrc[g];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      float av[2][KH], bv[NT][KH];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float* p = &s_in[a_base + ((2 * m + dy) * IN_PITCH + dx) * KCP];
+#pragma unroll
+        for (int j = 0; j < KH; j += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(p + j);
+          av[m][j] = t.x; av[m][j + 1] = t.y; av[m][j + 2] = t.z; av[m][j + 3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float* p = &s_w[b_base + (tap * N + n * 32) * KCP];
+#pragma unroll
+        for (int j = 0; j < KH; j += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(p + j);
+          bv[n][j] = t.x; bv[n][j + 1] = t.y; bv[n][j + 2] = t.z; bv[n][j + 3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KH; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j], bv[n][j], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  // accumulator register r of lane (i,h) in M-tile m: channel = n*32+i,
+  // pixel row = wave*4 + 2m + ((r>>1)&1), col = 2*(h + 2*(r>>2)) + (r&1)
+  const int store = a.store;
+  if (store == ST_NCHW) {
+    // transpose through LDS so each channel plane is written in 16-pixel rows
+    constexpr int OP = 257;
+    __syncthreads();
+    float* s_out = smem;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = n * 32 + i;
+      const float sc = a.scale[n0 + co], sh = a.shift[n0 + co];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ry = wave * 4 + 2 * m + ((r >> 1) & 1);
+          const int cx = 2 * (h + 2 * (r >> 2)) + (r & 1);
+          s_out[co * OP + ry * TILE + cx] = acc[m][n][r] * sc + sh;
+        }
+    }
+    __syncthreads();
+    const int ry = tid >> 4, cx = tid & 15;
+    const int y = y0 + ry, x = x0 + cx;
+    if (y < H && x < W) {
+      const size_t plane = (size_t)H * W;
+      const size_t pofs = (size_t)y * W + x;
+      if (a.act == ACT_SOFTMAX_C) {
+        float mx = -INFINITY;
+        for (int co = 0; co < a.cout; ++co) mx = fmaxf(mx, s_out[co * OP + tid]);
+        float sum = 0.f;
+        for (int co = 0; co < a.cout; ++co) sum += expf(s_out[co * OP + tid] - mx);
+        const float inv = 1.f / sum;
+        for (int co = 0; co < a.cout; ++co)
+          a.out0[((size_t)b * a.cout + co) * plane + pofs] = expf(s_out[co * OP + tid] - mx) * inv;
+      } else {
+        const int ns = a.nsplit;
+        for (int co = 0; co < a.cout; ++co) {
+          const float v = act_apply(s_out[co * OP + tid], a.act, co);
+          if (co < ns) a.out0[((size_t)b * ns + co) * plane + pofs] = v;
+          else a.out1[((size_t)b * (a.cout - ns) + (co - ns)) * plane + pofs] = v;
+        }
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = n0 + n * 32 + i;
+    const float sc = a.scale[co], sh = a.shift[co];
+    const bool cok = co < a.cout;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_apply(acc[m][n][r] * sc + sh, a.act, co);
+      const int ybase = y0 + wave * 4 + 2 * m;
+      if (store == ST_NHWC || store == ST_NHWC_BOTH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = ybase + ((r >> 1) & 1);
+          const int x = x0 + 2 * (h + 2 * (r >> 2)) + (r & 1);
+          if (cok && y < H && x < W) a.out0[(((size_t)b * H + y) * W + x) * a.os0 + a.oo0 + co] = v[r];
+        }
+      }
+      if (store == ST_NHWC_POOL || store == ST_NHWC_BOTH) {
+        const int Hp = H >> 1, Wp = W >> 1;
+        const int yp = ybase >> 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float p = fmaxf(fmaxf(v[4 * g], v[4 * g + 1]), fmaxf(v[4 * g + 2], v[4 * g + 3]));
+          const int xp = (x0 >> 1) + h + 2 * g;
+          if (cok && yp < Hp && xp < Wp) a.out1[(((size_t)b * Hp + yp) * Wp + xp) * a.os1 + a.oo1 + co] = p;
+        }
+      }
+      if (store == ST_SHUFFLE) {
+        // packed channel position co -> (sub-pixel, channel): sub = co / (cout/4), c = co % (cout/4);
+        // the packer permuted the rows so that original channel 4c + sub sits at position co.
+        const int cq = a.cout >> 2;
+        const int sub = co / cq, c = co - sub * cq;
+        const int ii = sub >> 1, jj = sub & 1;
+        const int H2 = 2 * H, W2 = 2 * W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = ybase + ((r >> 1) & 1);
+          const int x = x0 + 2 * (h + 2 * (r >> 2)) + (r & 1);
+          if (cok && y < H && x < W)
+            a.out0[(((size_t)b * H2 + 2 * y + ii) * W2 + 2 * x + jj) * a.os0 + a.oo0 + c] = v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int KC, int NT>
+static int launch_t(const ConvArgs& a, hipStream_t s) {
+  constexpr int KCP = KC + 4;
+  size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + 9 * NT * 32 * KCP) * sizeof(float);
+  const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
+  if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int grid = a.tiles_x * a.tiles_y * a.B;
+  const int groups = a.npad / (NT * 32);
+  if (a.store == ST_NCHW && groups != 1) return -1002;  // planar outputs are <= 64 channels
+  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT>), dim3(grid, groups), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
+  // npad is 32, or a multiple of 64 handled as npad/64 channel groups (blockIdx.y)
+  if (a.npad != 32 && a.npad % 64 != 0) return -1000;
+  const bool one = a.npad == 32;
+  if (kc == 16) return one ? launch_t<16, 1>(a, s) : launch_t<16, 2>(a, s);
+  if (kc == 8) return one ? launch_t<8, 1>(a, s) : launch_t<8, 2>(a, s);
+  return -1000;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backbone.conv1a (encoders.py:20-29): Cin = 3, reads the caller's NCHW frame directly, writes NHWC.
+// K = 27 is too shallow for the matrix cores and the layer is HBM-bound (11 FLOP/B): one thread
+// per pixel, all output channels in registers, weights broadcast from LDS.
+// ---------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_w[27 * CO];
+  __shared__ float s_sc[CO], s_sh[CO];
+  for (int t = threadIdx.x; t < 27 * CO; t += 256) s_w[t] = a.w[t];
+  for (int t = threadIdx.x; t < CO; t += 256) { s_sc[t] = a.scale[t]; s_sh[t] = a.shift[t]; }
+  __syncthreads();
+  const int H = a.H, W = a.W;
+  const size_t npix = (size_t)a.B * H * W;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < npix) {
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const int b = (int)(p / ((size_t)W * H));
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    float v[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      const float* plane = a.x + ((size_t)b * 3 + ci) * H * W;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = x + dx - 1;
+          v[ci * 9 + dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? plane[(size_t)yy * W + xx] : 0.f;
+        }
+      }
+    }
+    // k stays a real loop: fully unrolled, hipcc keeps all 27*CO weights live in registers
+#pragma unroll 3
+    for (int k = 0; k < 27; ++k) {
+      const float4* wr = reinterpret_cast<const float4*>(&s_w[k * CO]);
+      const float vk = v[k];
+#pragma unroll
+      for (int c = 0; c < CO; c += 4) {
+        const float4 w4 = wr[c / 4];
+        acc[c] = fmaf(vk, w4.x, acc[c]);
+        acc[c + 1] = fmaf(vk, w4.y, acc[c + 1]);
+        acc[c + 2] = fmaf(vk, w4.z, acc[c + 2]);
+        acc[c + 3] = fmaf(vk, w4.w, acc[c + 3]);
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + p * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) {
+      float4 o;
+      o.x = act_apply(acc[c] * s_sc[c] + s_sh[c], a.act, c);
+      o.y = act_apply(acc[c + 1] * s_sc[c + 1] + s_sh[c + 1], a.act, c + 1);
+      o.z = act_apply(acc[c + 2] * s_sc[c + 2] + s_sh[c + 2], a.act, c + 2);
+      o.w = act_apply(acc[c + 3] * s_sc[c + 3] + s_sh[c + 3], a.act, c + 3);
+      dst[c / 4] = o;
+    }
+  }
+}
+
+int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
+  const size_t npix = (size_t)a.B * a.H * a.W;
+  const int grid = (int)((npix + 255) / 256);
+  if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16>), dim3(grid), dim3(256), 0, s, a);
+  else return -1001;
+  return (int)hipGetLastError();
+}
+
+}  // namespace kp2d

@@ -1,0 +1,751 @@
+// Host side of the C ABI declared in include/kp2d.h: model description, weight packing, the per-call
+// launch plan and the measurement hooks.  All arithmetic happens in the HIP kernels of this directory;
+// there is no CPU compute path here (a missing device or library is an error, never a fallback).
+#include "../../include/kp2d.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kp2d_kernels.h"
+
+using namespace kp2d;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(KP2D_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+struct WeightSpec {
+  std::string key;
+  std::vector<int64_t> shape;
+  size_t numel() const {
+    size_t n = 1;
+    for (auto s : shape) n *= (size_t)s;
+    return n;
+  }
+};
+
+// one packed 3x3 convolution
+struct ConvPack {
+  std::string name;     // state-dict prefix, e.g. "backbone.conv2a"
+  bool bn = false;      // AnnotatedConvBnReLUModel (conv.weight + bn.*) vs plain Conv2d (weight + bias)
+  bool shuffle = false; // rows permuted for the PixelShuffle-folding store
+  int cin = 0, cout = 0, npad = 0, kc = 16;
+  size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
+  size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * 9 * npad * kc; }
+};
+
+struct ProfRec {
+  std::string layer, kernel;
+  double flops = 0, bytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+// first-fit arena over the caller's workspace
+struct Arena {
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_;
+  size_t cap = 0, high = 0;
+  void reset(size_t capacity) { cap = capacity; free_.assign(1, Blk{0, capacity}); high = 0; }
+  size_t alloc(size_t bytes) {
+    bytes = align_up(bytes);
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].size >= bytes) {
+        const size_t off = free_[i].off;
+        free_[i].off += bytes;
+        free_[i].size -= bytes;
+        if (free_[i].size == 0) free_.erase(free_.begin() + i);
+        high = std::max(high, off + bytes);
+        return off;
+      }
+    }
+    return (size_t)-1;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = align_up(bytes);
+    free_.push_back(Blk{off, bytes});
+    std::sort(free_.begin(), free_.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < free_.size();) {
+      if (free_[i].off + free_[i].size == free_[i + 1].off) {
+        free_[i].size += free_[i + 1].size;
+        free_.erase(free_.begin() + i + 1);
+      } else {
+        ++i;
+      }
+    }
+  }
+};
+
+// NHWC activation living in the workspace
+struct Act {
+  size_t off = 0, bytes = 0;
+  int C = 0, H = 0, W = 0;
+};
+
+}  // namespace
+
+struct kp2d_model {
+  kp2d_config cfg{};
+  int c1, c2, c3, c4, c5, d1;
+  std::vector<WeightSpec> specs;
+  std::map<std::string, int> spec_index;
+  std::map<std::string, std::vector<float>> host;
+  std::vector<ConvPack> convs;
+  std::map<std::string, int> conv_index;
+  size_t conv1a_w = 0, conv1a_sc = 0, conv1a_sh = 0;
+  size_t vlad_wa = 0, vlad_cent = 0;
+  size_t blob_floats = 0;
+  float* blob = nullptr;
+  bool finalized = false;
+  int chunk_frames = 0;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  size_t prof_used = 0;
+  hipStream_t prof_stream = nullptr;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// model description (state-dict layout: SURVEY.md App. C; constructors kp2dtiny.py:347-449 / :732-803)
+// ------------------------------------------------------------------------------------------------
+void add_spec(kp2d_model* m, const std::string& key, std::vector<int64_t> shape) {
+  m->spec_index[key] = (int)m->specs.size();
+  m->specs.push_back(WeightSpec{key, std::move(shape)});
+}
+
+void add_cbr(kp2d_model* m, const std::string& p, int ci, int co, bool shuffle = false) {
+  add_spec(m, p + ".conv.weight", {co, ci, 3, 3});
+  add_spec(m, p + ".bn.weight", {co});
+  add_spec(m, p + ".bn.bias", {co});
+  add_spec(m, p + ".bn.running_mean", {co});
+  add_spec(m, p + ".bn.running_var", {co});
+  ConvPack c;
+  c.name = p; c.bn = true; c.shuffle = shuffle; c.cin = ci; c.cout = co;
+  m->conv_index[p] = (int)m->convs.size();
+  m->convs.push_back(c);
+}
+
+void add_conv(kp2d_model* m, const std::string& p, int ci, int co, bool shuffle = false) {
+  add_spec(m, p + ".weight", {co, ci, 3, 3});
+  add_spec(m, p + ".bias", {co});
+  ConvPack c;
+  c.name = p; c.bn = false; c.shuffle = shuffle; c.cin = ci; c.cout = co;
+  m->conv_index[p] = (int)m->convs.size();
+  m->convs.push_back(c);
+}
+
+int describe(kp2d_model* m) {
+  const kp2d_config& g = m->cfg;
+  const int c1 = m->c1, c2 = m->c2, c3 = m->c3, c4 = m->c4, c5 = m->c5, d1 = m->d1;
+  const bool v3 = g.version == 3;
+  // backbone (encoders.py:20-99).  conv1a is packed separately (Cin = 3).
+  add_spec(m, "backbone.conv1a.conv.weight", {c1, 3, 3, 3});
+  add_spec(m, "backbone.conv1a.bn.weight", {c1});
+  add_spec(m, "backbone.conv1a.bn.bias", {c1});
+  add_spec(m, "backbone.conv1a.bn.running_mean", {c1});
+  add_spec(m, "backbone.conv1a.bn.running_var", {c1});
+  add_cbr(m, "backbone.conv1b", c1, c2);
+  add_cbr(m, "backbone.conv2a", c2, c2);
+  add_cbr(m, "backbone.conv2b", c2, c3);
+  add_cbr(m, "backbone.conv3a", c3, c3);
+  add_cbr(m, "backbone.conv3b", c3, c4);
+  add_cbr(m, "backbone.conv4a", c4, c4);
+  add_cbr(m, "backbone.conv4b", c4, c4);
+  if (v3) {
+    add_cbr(m, "score_loc_head.convDa", c4, c4);
+    add_conv(m, "score_loc_head.convDb", c4, 3);
+  } else {
+    add_cbr(m, "score_head.convDa", c4, c4);
+    add_conv(m, "score_head.convDb", c4, 1);
+    add_cbr(m, "loc_head.convDa", c4, c4);
+    add_conv(m, "loc_head.convDb", c4, 2);
+    add_cbr(m, "desc_head.convA", c4, c4);
+    add_conv(m, "desc_head.convB", c4, c3 * 4, /*shuffle=*/true);
+    add_cbr(m, "desc_head.confAa", c3 + c4, c4);
+    add_conv(m, "desc_head.confBb", c4, g.nfeatures);
+  }
+  const int ch = c5, cexp = c4 + c3;
+  const int last_in = v3 ? ch / 2 : ch;
+  if (g.use_attention) {
+    return fail(KP2D_ERR_UNSUPPORTED, "use_attention=1: the efficient-self-attention seg head is not built yet");
+  } else {
+    add_cbr(m, "seg_head.convs.0", c4, ch);
+    add_cbr(m, "seg_head.convs.1", ch, ch);
+    add_cbr(m, "seg_head.convs.2", ch, ch);
+    add_cbr(m, "seg_head.convs.3", ch, ch);
+    add_cbr(m, "seg_head.convs.4", ch, d1, true);
+    add_cbr(m, "seg_head.convs.5", ch + d1 / 4, ch);
+    add_cbr(m, "seg_head.convs.6", ch, d1, true);
+    add_cbr(m, "seg_head.convs.7", cexp, ch);
+    add_conv(m, "seg_head.convs.8", last_in, g.n_classes);
+  }
+  if (v3) add_conv(m, "seg_head.featB", ch / 2, g.nfeatures);
+  add_cbr(m, "vlad_head.convlad1", c4, g.encoder_dim);
+  add_cbr(m, "vlad_head.convlad2", g.encoder_dim, g.encoder_dim);
+  add_cbr(m, "vlad_head.convlad3", g.encoder_dim, g.encoder_dim);
+  add_spec(m, "vlad_head.netvlad.centroids", {g.num_clusters, g.encoder_dim});
+  add_spec(m, "vlad_head.netvlad.conv.weight", {g.num_clusters, g.encoder_dim, 1, 1});
+
+  // blob layout
+  size_t off = 0;
+  auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats, ALIGN / 4); return o; };
+  m->conv1a_w = take((size_t)27 * c1);
+  m->conv1a_sc = take(c1);
+  m->conv1a_sh = take(c1);
+  for (auto& c : m->convs) {
+    if (c.cin % 4) return fail(KP2D_ERR_UNSUPPORTED, "%s: input channels %d not a multiple of 4", c.name.c_str(), c.cin);
+    if (c.shuffle && (c.cout % 16)) return fail(KP2D_ERR_UNSUPPORTED, "%s: pixel-shuffle conv needs cout %% 16 == 0", c.name.c_str());
+    c.kc = (c.cin % 16 == 0) ? 16 : ((c.cin % 8 == 0) ? 8 : 16);
+    c.npad = c.cout <= 32 ? 32 : (c.cout + 63) / 64 * 64;
+    c.w_off = take(c.w_floats());
+    c.sc_off = take(c.npad);
+    c.sh_off = take(c.npad);
+  }
+  m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
+  m->vlad_cent = take((size_t)g.num_clusters * g.encoder_dim);
+  m->blob_floats = off;
+  return KP2D_OK;
+}
+
+const std::vector<float>* host_get(const kp2d_model* m, const std::string& key) {
+  auto it = m->host.find(key);
+  return it == m->host.end() ? nullptr : &it->second;
+}
+
+// BatchNorm2d eval: y = (x - mean) / sqrt(var + 1e-5) * gamma + beta  ->  y = x * scale + shift
+void bn_fold(const kp2d_model* m, const std::string& p, int co, float* scale, float* shift) {
+  const auto& g = *host_get(m, p + ".weight");
+  const auto& b = *host_get(m, p + ".bias");
+  const auto& mu = *host_get(m, p + ".running_mean");
+  const auto& var = *host_get(m, p + ".running_var");
+  for (int c = 0; c < co; ++c) {
+    const float s = g[c] / std::sqrt(var[c] + 1e-5f);
+    scale[c] = s;
+    shift[c] = b[c] - mu[c] * s;
+  }
+}
+
+int pack(kp2d_model* m, std::vector<float>& blob) {
+  for (const auto& s : m->specs)
+    if (!host_get(m, s.key)) return fail(KP2D_ERR_WEIGHT, "missing tensor '%s'", s.key.c_str());
+  blob.assign(m->blob_floats, 0.f);
+  const int c1 = m->c1;
+  {
+    const auto& w = *host_get(m, "backbone.conv1a.conv.weight");   // [c1][3][3][3]
+    for (int co = 0; co < c1; ++co)
+      for (int k = 0; k < 27; ++k) blob[m->conv1a_w + (size_t)k * c1 + co] = w[(size_t)co * 27 + k];
+    bn_fold(m, "backbone.conv1a.bn", c1, &blob[m->conv1a_sc], &blob[m->conv1a_sh]);
+  }
+  for (const auto& c : m->convs) {
+    const auto& w = *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][cin][3][3]
+    std::vector<float> sc(c.cout), sh(c.cout);
+    if (c.bn) {
+      bn_fold(m, c.name + ".bn", c.cout, sc.data(), sh.data());
+    } else {
+      const auto& b = *host_get(m, c.name + ".bias");
+      for (int i = 0; i < c.cout; ++i) { sc[i] = 1.f; sh[i] = b[i]; }
+    }
+    const int ng = c.npad <= 32 ? 32 : 64;          // channels per workgroup group
+    const int ngroups = c.npad / ng;
+    const int nchunk = (c.cin + c.kc - 1) / c.kc;
+    const int cq = c.cout / 4;
+    for (int q = 0; q < c.npad; ++q) {
+      // packed position q -> original output channel (PixelShuffle: out[c,2h+i,2w+j] = in[4c+2i+j,h,w])
+      int co = -1;
+      if (q < c.cout) co = c.shuffle ? 4 * (q % cq) + (q / cq) : q;
+      blob[c.sc_off + q] = co >= 0 ? sc[co] : 0.f;
+      blob[c.sh_off + q] = co >= 0 ? sh[co] : 0.f;
+      if (co < 0) continue;
+      const int grp = q / ng, n = q % ng;
+      for (int ci = 0; ci < c.cin; ++ci) {
+        const int chk = ci / c.kc, kk = ci % c.kc;
+        for (int tap = 0; tap < 9; ++tap) {
+          const size_t dst = c.w_off + ((((size_t)grp * nchunk + chk) * 9 + tap) * ng + n) * c.kc + kk;
+          blob[dst] = w[((size_t)co * c.cin + ci) * 9 + tap];
+        }
+      }
+    }
+    (void)ngroups;
+  }
+  const auto& wa = *host_get(m, "vlad_head.netvlad.conv.weight");
+  const auto& ce = *host_get(m, "vlad_head.netvlad.centroids");
+  std::copy(wa.begin(), wa.end(), blob.begin() + m->vlad_wa);
+  std::copy(ce.begin(), ce.end(), blob.begin() + m->vlad_cent);
+  return KP2D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch plan
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+  kp2d_model* m;
+  hipStream_t stream;
+  char* ws;
+  Arena arena;
+  bool dry = false;       // only size the arena
+  int B, H, W;
+  int rc = KP2D_OK;
+
+  Act alloc(int C, int H_, int W_) {
+    Act a;
+    a.C = C; a.H = H_; a.W = W_;
+    a.bytes = (size_t)B * H_ * W_ * C * sizeof(float);
+    a.off = arena.alloc(a.bytes);
+    if (a.off == (size_t)-1 && rc == KP2D_OK) rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
+    return a;
+  }
+  void release(const Act& a) { arena.release(a.off, a.bytes); }
+  float* ptr(const Act& a) const { return reinterpret_cast<float*>(ws + a.off); }
+
+  void prof_begin(const std::string& layer, const char* kernel, double flops, double bytes) {
+    if (!m->profiling || dry) return;
+    if (m->prof_used == m->prof.size()) {
+      ProfRec r;
+      hipEventCreate(&r.e0);
+      hipEventCreate(&r.e1);
+      m->prof.push_back(r);
+    }
+    ProfRec& r = m->prof[m->prof_used];
+    r.layer = layer; r.kernel = kernel; r.flops = flops; r.bytes = bytes;
+    hipEventRecord(r.e0, stream);
+  }
+  void prof_end() {
+    if (!m->profiling || dry) return;
+    hipEventRecord(m->prof[m->prof_used].e1, stream);
+    ++m->prof_used;
+  }
+  void check(int e, const char* what) {
+    if (e != 0 && rc == KP2D_OK) rc = fail(KP2D_ERR_HIP, "%s: launch failed (%d: %s)", what, e,
+                                           e > 0 ? hipGetErrorString((hipError_t)e) : "unsupported shape");
+  }
+
+  // generic 3x3 conv: in1 may be null (no concat).  Channel slices via (c, off).
+  void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
+            float* out0, int os0, int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
+    if (rc != KP2D_OK) return;
+    const ConvPack& c = m->convs[m->conv_index.at(name)];
+    if (dry) return;
+    ConvArgs a{};
+    a.in0 = ptr(in0); a.c0 = c0; a.s0 = in0.C; a.o0 = o0;
+    if (in1) { a.in1 = ptr(*in1); a.c1 = in1->C; a.s1 = in1->C; a.o1 = 0; }
+    else { a.in1 = a.in0; a.c1 = 0; a.s1 = in0.C; a.o1 = 0; }
+    a.w = m->blob + c.w_off; a.scale = m->blob + c.sc_off; a.shift = m->blob + c.sh_off;
+    a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
+    a.B = B; a.H = Hc; a.W = Wc; a.cin = c.cin; a.cout = c.cout; a.npad = c.npad;
+    a.act = act; a.store = store; a.nsplit = nsplit;
+    a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
+    if (a.c0 + a.c1 != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), a.c0 + a.c1, c.cin); return; }
+    const double px = (double)B * Hc * Wc;
+    prof_begin(name, c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>", 2.0 * 9 * c.cin * c.cout * px,
+               4.0 * px * (c.cin + c.cout) + 4.0 * 9 * c.cin * c.cout);
+    check(launch_conv3x3(a, c.kc, stream), name.c_str());
+    prof_end();
+  }
+  // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
+  Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr) {
+    const ConvPack& c = m->convs[m->conv_index.at(name)];
+    const int act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
+    const int Hc = in0.H, Wc = in0.W;
+    Act out{};
+    if (store == ST_NHWC) {
+      out = alloc(c.cout, Hc, Wc);
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, Hc, Wc);
+    } else if (store == ST_NHWC_POOL) {
+      out = alloc(c.cout, Hc / 2, Wc / 2);
+      conv(name, in0, in0.C, 0, in1, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, Hc, Wc);
+    } else if (store == ST_NHWC_BOTH) {
+      out = alloc(c.cout, Hc, Wc);
+      *pooled = alloc(c.cout, Hc / 2, Wc / 2);
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, dry ? nullptr : ptr(*pooled),
+           c.cout, 0, 0, Hc, Wc);
+    } else {  // ST_SHUFFLE
+      out = alloc(c.cout / 4, Hc * 2, Wc * 2);
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
+    }
+    return out;
+  }
+};
+
+struct FwdOut {
+  const float* x;
+  float *score, *shift, *feat, *seg, *vlad;
+};
+
+// KP2DTinyV2.forward (kp2dtiny.py:552-591) / KP2DTinyV3.forward (:906-957) as a launch sequence
+void build(Plan& P, const FwdOut& o, uint32_t flags) {
+  kp2d_model* m = P.m;
+  const kp2d_config& g = m->cfg;
+  const bool v3 = g.version == 3;
+  const int lk = g.leaky_relu ? ACT_LEAKY : ACT_RELU;
+  const int H = P.H, W = P.W, B = P.B;
+
+  // ---- backbone (encoders.py:105-129) ----
+  Act t1a = P.alloc(m->c1, H, W);
+  if (!P.dry && P.rc == KP2D_OK) {
+    Conv1aArgs a{};
+    a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
+    a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk;
+    const double px = (double)B * H * W;
+    P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 27 * m->c1 * px, 4.0 * px * (3 + m->c1));
+    P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
+    P.prof_end();
+  }
+  Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC);
+  P.release(t1a);
+  Act t2a = P.cbr("backbone.conv2a", p1, nullptr, ST_NHWC);
+  P.release(p1);
+  Act t2b = P.cbr("backbone.conv2b", t2a, nullptr, g.downsample >= 3 ? ST_NHWC_POOL : ST_NHWC);
+  P.release(t2a);
+  Act t3a = P.cbr("backbone.conv3a", t2b, nullptr, ST_NHWC);
+  P.release(t2b);
+  Act xp{};
+  Act skip = P.cbr("backbone.conv3b", t3a, nullptr, ST_NHWC_BOTH, &xp);   // downsample >= 1 always
+  P.release(t3a);
+  Act t4a = P.cbr("backbone.conv4a", xp, nullptr, ST_NHWC);
+  P.release(xp);
+  Act xb = P.cbr("backbone.conv4b", t4a, nullptr, ST_NHWC);
+  P.release(t4a);
+  const int Hc = xb.H, Wc = xb.W, H2 = skip.H, W2 = skip.W;
+
+  // ---- score / location heads (heads.py:28-35; sigmoid/tanh kp2dtiny.py:574-575, :927-935) ----
+  if (v3) {
+    Act s1 = P.cbr("score_loc_head.convDa", xb, nullptr, ST_NHWC);
+    P.conv("score_loc_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID0_TANH, ST_NCHW, o.score, 0, 0, o.shift, 0, 0, 1, Hc, Wc);
+    P.release(s1);
+  } else {
+    Act s1 = P.cbr("score_head.convDa", xb, nullptr, ST_NHWC);
+    P.conv("score_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID, ST_NCHW, o.score, 0, 0, nullptr, 0, 0, 1, Hc, Wc);
+    P.release(s1);
+    Act l1 = P.cbr("loc_head.convDa", xb, nullptr, ST_NHWC);
+    P.conv("loc_head.convDb", l1, l1.C, 0, nullptr, ACT_TANH, ST_NCHW, o.shift, 0, 0, nullptr, 0, 0, 2, Hc, Wc);
+    P.release(l1);
+    // ---- descriptor head (heads.py:91-104) ----
+    Act d1 = P.cbr("desc_head.convA", xb, nullptr, ST_NHWC);
+    const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
+    Act d2 = P.alloc(cB.cout / 4, H2, W2);
+    P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+    P.release(d1);
+    Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
+    P.release(d2);
+    P.conv("desc_head.confBb", d3, d3.C, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
+    P.release(d3);
+  }
+
+  // ---- segmentation head (segmentation.py:126-157 V2 / :321-347 V3) ----
+  {
+    Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
+    Act g1 = P.cbr("seg_head.convs.1", g0, nullptr, ST_NHWC_POOL);
+    P.release(g0);
+    Act g2 = P.cbr("seg_head.convs.2", g1, nullptr, ST_NHWC);
+    P.release(g1);
+    Act g3 = P.cbr("seg_head.convs.3", g2, nullptr, ST_NHWC);
+    P.release(g2);
+    Act g4 = P.cbr("seg_head.convs.4", g3, nullptr, ST_SHUFFLE);
+    P.release(g3);
+    Act g5 = P.cbr("seg_head.convs.5", g4, &xb, ST_NHWC);
+    P.release(g4);
+    Act g6 = P.cbr("seg_head.convs.6", g5, nullptr, ST_SHUFFLE);
+    P.release(g5);
+    Act g7 = P.cbr("seg_head.convs.7", g6, &skip, ST_NHWC);
+    P.release(g6);
+    if (v3) {
+      const int half = g7.C / 2;   // dim_split = c_hidden // 2 (segmentation.py:190, :339-343)
+      P.conv("seg_head.featB", g7, half, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
+      const bool sm = (flags & KP2D_FWD_EVAL) && !g.remove_softmax;
+      P.conv("seg_head.convs.8", g7, half, g7.C - half, nullptr, sm ? ACT_SOFTMAX_C : ACT_NONE, ST_NCHW, o.seg, 0, 0,
+             nullptr, 0, 0, g.n_classes, H2, W2);
+    } else {
+      P.conv("seg_head.convs.8", g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
+    }
+    P.release(g7);
+  }
+
+  // ---- VPR head (vpr.py:78-89) + NetVLAD (netvlad.py:79-106) ----
+  {
+    Act v1 = P.cbr("vlad_head.convlad1", xb, nullptr, ST_NHWC);
+    Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
+    P.release(v1);
+    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
+    P.release(v2);
+    const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
+    const int ns = netvlad_nsplit(S);
+    Act part{};
+    part.bytes = (size_t)B * ns * ((size_t)K * C + K) * sizeof(float);
+    part.off = P.arena.alloc(part.bytes);
+    if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
+    if (!P.dry && P.rc == KP2D_OK) {
+      VladArgs a{};
+      a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
+      a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns;
+      P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
+      P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
+      P.prof_end();
+    }
+    P.arena.release(part.off, part.bytes);
+    P.release(v3a);
+  }
+  P.release(xb);
+  P.release(skip);
+}
+
+int validate_shape(const kp2d_model* m, int B, int H, int W) {
+  if (B < 1) return fail(KP2D_ERR_ARG, "B must be >= 1");
+  if (H < 16 || W < 16 || (H % 8) || (W % 8)) return fail(KP2D_ERR_ARG, "H and W must be multiples of 8 and >= 16 (got %dx%d)", H, W);
+  if (m->cfg.downsample != 2) return fail(KP2D_ERR_UNSUPPORTED, "downsample=%d (only 2 is built)", m->cfg.downsample);
+  return KP2D_OK;
+}
+
+int auto_chunk(const kp2d_model* m, int B, int H, int W) {
+  if (m->chunk_frames > 0) return std::min(B, m->chunk_frames);
+  // keep one sub-batch's live activations (~60 B per input pixel per unit of c4/64) inside the Infinity Cache
+  const double per_frame = 60.0 * H * W * (m->c4 / 64.0) * 4.0;
+  int c = (int)(192.0 * 1024 * 1024 / per_frame);
+  c = std::max(4, std::min(c, 32));
+  return std::min(B, c);
+}
+
+size_t plan_bytes(kp2d_model* m, int Bc, int H, int W) {
+  Plan P{};
+  P.m = m; P.stream = nullptr; P.ws = nullptr; P.dry = true; P.B = Bc; P.H = H; P.W = W;
+  P.arena.reset((size_t)1 << 46);
+  FwdOut o{};
+  build(P, o, 0);
+  return P.rc == KP2D_OK ? P.arena.high : 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* kp2d_last_error(void) { return g_err.c_str(); }
+int32_t kp2d_abi_version(void) { return KP2D_ABI_VERSION; }
+
+int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
+  if (!cfg || !out) return fail(KP2D_ERR_ARG, "null argument");
+  if (cfg->struct_size != (int32_t)sizeof(kp2d_config)) return fail(KP2D_ERR_ARG, "kp2d_config.struct_size mismatch");
+  if (cfg->version != 2 && cfg->version != 3) return fail(KP2D_ERR_ARG, "version must be 2 or 3");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(KP2D_ERR_HIP, "no HIP device visible: this library has no CPU path");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(KP2D_ERR_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
+  auto* m = new kp2d_model();
+  m->cfg = *cfg;
+  m->c1 = cfg->channel_dims[0]; m->c2 = cfg->channel_dims[1]; m->c3 = cfg->channel_dims[2];
+  m->c4 = cfg->channel_dims[3]; m->c5 = cfg->channel_dims[4]; m->d1 = cfg->channel_dims[5];
+  if (m->c1 != 16) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "channel_dims[0]=%d (conv1a kernel is built for 16)", cfg->channel_dims[0]); }
+  if (cfg->nfeatures != 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "nfeatures=%d (only 32 is built)", cfg->nfeatures); }
+  if (cfg->n_classes < 1 || cfg->n_classes > 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "n_classes must be in [1,32]"); }
+  int rc = describe(m);
+  if (rc != KP2D_OK) { delete m; return rc; }
+  *out = m;
+  return KP2D_OK;
+}
+
+void kp2d_destroy(kp2d_model* m) {
+  if (!m) return;
+  if (m->blob) hipFree(m->blob);
+  for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  delete m;
+}
+
+int kp2d_num_weights(const kp2d_model* m) { return m ? (int)m->specs.size() : 0; }
+
+int kp2d_weight_info(const kp2d_model* m, int index, const char** key, int64_t shape[4], int* ndim) {
+  if (!m || index < 0 || index >= (int)m->specs.size()) return fail(KP2D_ERR_ARG, "weight index out of range");
+  const WeightSpec& s = m->specs[index];
+  if (key) *key = s.key.c_str();
+  if (ndim) *ndim = (int)s.shape.size();
+  if (shape) for (size_t i = 0; i < s.shape.size() && i < 4; ++i) shape[i] = s.shape[i];
+  return KP2D_OK;
+}
+
+int kp2d_set_weight(kp2d_model* m, const char* key, const float* host, const int64_t* shape, int ndim) {
+  if (!m || !key || !host || (!shape && ndim > 0)) return fail(KP2D_ERR_ARG, "null argument");
+  std::string k(key);
+  if (k.size() > 20 && k.compare(k.size() - 20, 20, ".num_batches_tracked") == 0) return KP2D_OK;
+  auto it = m->spec_index.find(k);
+  if (it == m->spec_index.end()) return fail(KP2D_ERR_WEIGHT, "unexpected key '%s'", key);
+  const WeightSpec& s = m->specs[it->second];
+  bool same = (int)s.shape.size() == ndim;
+  for (int i = 0; same && i < ndim; ++i) same = s.shape[i] == shape[i];
+  if (!same) return fail(KP2D_ERR_WEIGHT, "shape mismatch for '%s'", key);
+  m->host[k].assign(host, host + s.numel());
+  m->finalized = false;
+  return KP2D_OK;
+}
+
+int kp2d_finalize_weights(kp2d_model* m) {
+  if (!m) return fail(KP2D_ERR_ARG, "null model");
+  std::vector<float> blob;
+  int rc = pack(m, blob);
+  if (rc != KP2D_OK) return rc;
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  if (!m->blob) HIP_TRY(hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float)));
+  HIP_TRY(hipMemcpy(m->blob, blob.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice));
+  m->finalized = true;
+  return KP2D_OK;
+}
+
+size_t kp2d_packed_bytes(const kp2d_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
+
+int kp2d_export_packed(const kp2d_model* m, void* dev_dst, void* stream) {
+  if (!m || !dev_dst) return fail(KP2D_ERR_ARG, "null argument");
+  if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised");
+  HIP_TRY(hipMemcpyAsync(dev_dst, m->blob, m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return KP2D_OK;
+}
+
+int kp2d_import_packed(kp2d_model* m, const void* dev_src, void* stream) {
+  if (!m || !dev_src) return fail(KP2D_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  if (!m->blob) HIP_TRY(hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(m->blob, dev_src, m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  m->finalized = true;
+  return KP2D_OK;
+}
+
+size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
+  if (!m || validate_shape(m, B, H, W) != KP2D_OK) return 0;
+  const int chunk = auto_chunk(m, B, H, W);
+  return plan_bytes(const_cast<kp2d_model*>(m), chunk, H, W);
+}
+
+int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
+                 float* feat, float* seg, float* vlad, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !x || !score || !shift || !feat || !seg || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
+  if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised (kp2d_finalize_weights / kp2d_import_packed)");
+  int rc = validate_shape(m, B, H, W);
+  if (rc != KP2D_OK) return rc;
+  if ((uintptr_t)workspace % ALIGN) return fail(KP2D_ERR_WORKSPACE, "workspace must be %zu-byte aligned", ALIGN);
+  const int chunk = auto_chunk(m, B, H, W);
+  const size_t need = plan_bytes(m, chunk, H, W);
+  if (need == 0) return KP2D_ERR_WORKSPACE;
+  if (workspace_bytes < need) return fail(KP2D_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  const kp2d_config& g = m->cfg;
+  const size_t Hc = H / 4, Wc = W / 4, H2 = H / 2, W2 = W / 2;
+  m->prof_used = 0;
+  m->prof_stream = (hipStream_t)stream;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    Plan P{};
+    P.m = m; P.stream = (hipStream_t)stream; P.ws = (char*)workspace; P.dry = false;
+    P.B = std::min(chunk, B - b0); P.H = H; P.W = W;
+    P.arena.reset(workspace_bytes);
+    FwdOut o{};
+    o.x = x + (size_t)b0 * 3 * H * W;
+    o.score = score + (size_t)b0 * Hc * Wc;
+    o.shift = shift + (size_t)b0 * 2 * Hc * Wc;
+    o.feat = feat + (size_t)b0 * g.nfeatures * H2 * W2;
+    o.seg = seg + (size_t)b0 * g.n_classes * H2 * W2;
+    o.vlad = vlad + (size_t)b0 * g.num_clusters * g.encoder_dim;
+    build(P, o, flags);
+    if (P.rc != KP2D_OK) return P.rc;
+  }
+  return KP2D_OK;
+}
+
+int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,
+              int H, int W, int Hc, int Wc, int feat_c, int Hf, int Wf, int seg_c, int Hs, int Ws, float* score_out,
+              float* coord, float* desc, int64_t* seg_ids, void* stream) {
+  if (!m || !score || !shift || !score_out || !coord) return fail(KP2D_ERR_ARG, "null argument");
+  if (desc && !feat) return fail(KP2D_ERR_ARG, "desc requested without feat");
+  if (seg_ids && !seg) return fail(KP2D_ERR_ARG, "seg_ids requested without seg");
+  PostArgs a{};
+  a.score_in = score; a.shift = shift; a.feat = feat; a.score_out = score_out; a.coord = coord; a.desc = desc;
+  a.B = B; a.C = feat_c; a.Hc = Hc; a.Wc = Wc; a.Hf = Hf; a.Wf = Wf; a.H = H; a.W = W;
+  a.cell = 1 << m->cfg.downsample;
+  a.cross_ratio = 2.0f;   // kp2dtiny.py:339
+  if (!desc) a.C = 32;
+  int e = launch_post(a, (hipStream_t)stream);
+  if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "post kernel: %d (descriptor channels %d)", e, feat_c);
+  if (seg_ids) {
+    ArgmaxArgs g{seg, seg_ids, B, seg_c, Hs * Ws};
+    e = launch_seg_argmax(g, (hipStream_t)stream);
+    if (e) return fail(KP2D_ERR_HIP, "argmax kernel: %d", e);
+  }
+  return KP2D_OK;
+}
+
+int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t* idx, float* val, int32_t* count,
+                     void* stream) {
+  if (!score || !idx || !count) return fail(KP2D_ERR_ARG, "null argument");
+  if (k < 1 || k > 4096) return fail(KP2D_ERR_ARG, "k must be in [1,4096]");
+  TopkArgs a{score, B, n, k, thr, idx, val, count};
+  int e = launch_topk(a, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "topk kernel: %d", e);
+  return KP2D_OK;
+}
+
+int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
+                          float* pts, float* dsel, void* stream) {
+  if (!coord || !desc || !idx || !pts || !dsel) return fail(KP2D_ERR_ARG, "null argument");
+  GatherArgs a{coord, desc, idx, pts, dsel, B, C, n, k};
+  int e = launch_gather(a, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "gather kernel: %d", e);
+  return KP2D_OK;
+}
+
+int kp2d_set_profiling(kp2d_model* m, int on) {
+  if (!m) return fail(KP2D_ERR_ARG, "null model");
+  m->profiling = on != 0;
+  m->prof_used = 0;
+  return KP2D_OK;
+}
+
+int kp2d_profile_count(kp2d_model* m) {
+  if (!m) return fail(KP2D_ERR_ARG, "null model");
+  if (!m->profiling) return fail(KP2D_ERR_STATE, "profiling is off");
+  if (m->prof_used) {
+    hipError_t e = hipEventSynchronize(m->prof[m->prof_used - 1].e1);
+    if (e != hipSuccess) return fail(KP2D_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+  }
+  return (int)m->prof_used;
+}
+
+int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** kernel, float* ms, double* flops,
+                     double* bytes) {
+  if (!m || index < 0 || (size_t)index >= m->prof_used) return fail(KP2D_ERR_ARG, "profile index out of range");
+  ProfRec& r = m->prof[index];
+  if (layer) *layer = r.layer.c_str();
+  if (kernel) *kernel = r.kernel.c_str();
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  if (ms) HIP_TRY(hipEventElapsedTime(ms, r.e0, r.e1));
+  return KP2D_OK;
+}
+
+int kp2d_set_chunk_frames(kp2d_model* m, int frames) {
+  if (!m || frames < 0) return fail(KP2D_ERR_ARG, "bad argument");
+  m->chunk_frames = frames;
+  return KP2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Internal launch interface between the C-ABI host code (kp2d_api.cpp) and the HIP kernels.
+// Not part of the public ABI (that is include/kp2d.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kp2d {
+
+// ---- activation / epilogue selectors -------------------------------------------------------
+enum Act : int {
+  ACT_NONE = 0,
+  ACT_LEAKY = 1,           // LeakyReLU(0.01)       modules/base.py:33
+  ACT_RELU = 2,            // ReLU (to_mcu configs) modules/base.py:35
+  ACT_SIGMOID = 3,         // score head            models/kp2dtiny.py:574
+  ACT_TANH = 4,            // loc head              models/kp2dtiny.py:575
+  ACT_SIGMOID0_TANH = 5,   // V3 fused score/loc: ch0 sigmoid, ch1..2 tanh  models/kp2dtiny.py:927-935
+  ACT_SOFTMAX_C = 6,       // V3 eval: Softmax2d over classes                models/kp2dtiny.py:942-943
+};
+
+enum Store : int {
+  ST_NHWC = 0,             // out0[pixel][os0] (+oo0), full resolution
+  ST_NHWC_POOL = 1,        // out1 = MaxPool2d(2,2) of the activation only
+  ST_NHWC_BOTH = 2,        // out0 full-res AND out1 pooled (conv3b: skip + x)
+  ST_SHUFFLE = 3,          // PixelShuffle(2) folded into the store: out0 is the 2H x 2W NHWC tensor
+  ST_NCHW = 4,             // API-facing planar output; channels [0,nsplit) -> out0, [nsplit,cout) -> out1
+};
+
+// One 3x3 / stride 1 / pad 1 convolution over an NHWC activation that may be the channel-concat
+// of two tensors (torch.cat([up, skip], 1): heads.py:99, segmentation.py:141,149).
+struct ConvArgs {
+  const float* in0; int c0, s0, o0;   // channels taken, pixel stride (floats), first channel
+  const float* in1; int c1, s1, o1;
+  const float* w;                     // packed [cin_pad/KC][9][npad][KC]
+  const float* scale;                 // [npad]  BN: gamma/sqrt(var+eps); bias conv: 1
+  const float* shift;                 // [npad]  BN: beta - mean*scale;   bias conv: bias
+  float* out0; int os0, oo0;
+  float* out1; int os1, oo1;
+  int B, H, W;                        // conv resolution
+  int cin, cout, npad;
+  int act, store, nsplit;
+  int tiles_x, tiles_y;
+};
+
+struct Conv1aArgs {                   // backbone.conv1a: NCHW RGB in -> NHWC out, Cin = 3
+  const float* x;                     // [B,3,H,W]
+  const float* w;                     // [27][cout]  (k = ci*9 + dy*3 + dx)
+  const float* scale; const float* shift;
+  float* out; int B, H, W, cout, act;
+};
+
+int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s);
+int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
+
+// ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
+struct VladArgs {
+  const float* x;        // encoder output, NHWC [B][S][C]
+  const float* wa;       // soft-assign 1x1 conv weight [K][C]
+  const float* cent;     // centroids [K][C]
+  float* part;           // workspace [B][nsplit][K*C + K]
+  float* out;            // [B][K*C]
+  int B, S, C, K, nsplit;
+};
+int launch_netvlad(const VladArgs& a, hipStream_t s);
+int netvlad_nsplit(int S);
+
+// ---- post-processing (models/kp2dtiny.py:593-647 / 959-1015) -------------------------------
+struct PostArgs {
+  const float* score_in;  // [B,1,Hc,Wc] sigmoid score
+  const float* shift;     // [B,2,Hc,Wc] tanh shift
+  const float* feat;      // [B,C,Hf,Wf] dense descriptors (NCHW)
+  float* score_out;       // [B,1,Hc,Wc]
+  float* coord;           // [B,2,Hc,Wc] pixels, ch0 = x
+  float* desc;            // [B,C,Hc,Wc] sampled + L2 normalised (nullptr: training mode, no sampling)
+  int B, C, Hc, Wc, Hf, Wf, H, W, cell;
+  float cross_ratio;
+};
+int launch_post(const PostArgs& a, hipStream_t s);
+
+struct ArgmaxArgs { const float* seg; int64_t* ids; int B, C, HW; };
+int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s);
+
+// ---- keypoint selection (callers K1/K2/K3) ----------------------------------
+struct TopkArgs {
+  const float* score;   // [B][n]
+  int B, n, k;
+  float thr;            // keep score > thr; pass -inf for plain top-k
+  int32_t* idx;         // [B][k] flat cell indices, score desc / index asc on ties; -1 padded
+  float* val;           // [B][k] scores (0 padded), may be nullptr
+  int32_t* count;       // [B]
+};
+int launch_topk(const TopkArgs& a, hipStream_t s);
+
+struct GatherArgs {     // gather coords / descriptors of selected cells into [B][k][2] / [B][k][C]
+  const float* coord; const float* desc; const int32_t* idx;
+  float* pts; float* dsel; int B, C, n, k;
+};
+int launch_gather(const GatherArgs& a, hipStream_t s);
+
+// ---- small layout / elementwise kernels -----------------------------------------------------
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s);
+
+}  // namespace kp2d

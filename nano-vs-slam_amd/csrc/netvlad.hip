@@ -1,0 +1,173 @@
+// NetVLAD pooling (modules/aggregators/netvlad.py:79-106), restated so the [K][C][S] residual tensor
+// (78.6 MB / frame at 240x320) is never formed:
+//     xh      = x / max(||x||_C, 1e-12)                          (F.normalize, :83)
+//     a[s,k]  = softmax_k( sum_c Wa[k,c] xh[s,c] )               (1x1 conv without bias + softmax, :86-89)
+//     V[k,c]  = sum_s a[s,k] xh[s,c]  -  (sum_s a[s,k]) cent[k,c]   (== sum_s a (xh - cent), :94-100)
+//     V[k,:] /= max(||V[k,:]||, 1e-12); v = flatten(V) (k-major); v /= max(||v||, 1e-12)   (:102-104)
+//
+// Two launches, both with a fixed summation order (bit-reproducible, no atomics):
+//   pass 1: grid (nsplit, B); each workgroup walks its pixel slab in 64-pixel tiles held in LDS and
+//           keeps its K*C partial sums in registers; writes one partial [K*C + K] per (frame, split).
+//   pass 2: grid (B); sums the partials in split order, subtracts rowsum * centroid, does both
+//           normalisations with wavefront shuffles + one LDS exchange.
+// The input is the NHWC output of vlad_head.convlad3, so a pixel's C channels are one contiguous line.
+#include "kp2d_kernels.h"
+
+namespace kp2d {
+
+constexpr int VT = 64;  // pixels per LDS tile
+
+int netvlad_nsplit(int S) {
+  int n = (S + 319) / 320;  // ~5 tiles of 64 pixels per workgroup
+  return n < 1 ? 1 : n;
+}
+
+__global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.C, K = a.K, S = a.S;
+  const int CP = C + 1, KP = K + 1;
+  float* s_w = sm;                 // [K][CP]
+  float* s_x = s_w + K * CP;       // [VT][CP]
+  float* s_a = s_x + VT * CP;      // [VT][KP]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int per = (S + a.nsplit - 1) / a.nsplit;
+  const int s_begin = split * per;
+  const int s_end = min(S, s_begin + per);
+
+  for (int e = tid; e < K * C; e += 256) s_w[(e / C) * CP + (e % C)] = a.wa[e];
+
+  const int KC_ = K * C;
+  const int nown = (KC_ + 255) / 256;          // <= 16
+  float vacc[16];
+  int vk[16], vc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    vacc[j] = 0.f;
+    const int e = tid + 256 * j;
+    vk[j] = (e < KC_) ? e / C : 0;
+    vc[j] = (e < KC_) ? e % C : 0;
+  }
+  float asum = 0.f;                             // thread t < K owns rowsum(a)[t]
+
+  const int p = tid >> 2, q = tid & 3;          // 4 threads per pixel
+  const int cq = C >> 2, kq = K >> 2;
+  const float* xb = a.x + (size_t)b * S * C;
+
+  for (int t0 = s_begin; t0 < s_end; t0 += VT) {
+    const int np = min(VT, s_end - t0);
+    __syncthreads();
+    for (int e = tid; e < VT * C; e += 256) {
+      const int pp = e / C, cc = e - pp * C;
+      s_x[pp * CP + cc] = (pp < np) ? xb[(size_t)(t0 + pp) * C + cc] : 0.f;
+    }
+    __syncthreads();
+    // descriptor-wise L2 normalisation
+    float ss = 0.f;
+    for (int c = q * cq; c < (q + 1) * cq; ++c) { const float v = s_x[p * CP + c]; ss = fmaf(v, v, ss); }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = q * cq; c < (q + 1) * cq; ++c) s_x[p * CP + c] *= inv;
+    __syncthreads();
+    // soft assignment: this thread owns clusters [q*kq, (q+1)*kq) of pixel p
+    float lg[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < kq) {
+        const float* wr = &s_w[(q * kq + j) * CP];
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) d = fmaf(wr[c], s_x[p * CP + c], d);
+        lg[j] = d;
+        mx = fmaxf(mx, d);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < kq) { lg[j] = expf(lg[j] - mx); se += lg[j]; }
+    se += __shfl_xor(se, 1);
+    se += __shfl_xor(se, 2);
+    const float rs = (p < np) ? 1.f / se : 0.f;   // pixels past the slab contribute nothing
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < kq) s_a[p * KP + q * kq + j] = lg[j] * rs;
+    __syncthreads();
+    // aggregation
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < nown) {
+        float acc = vacc[j];
+        const int k = vk[j], c = vc[j];
+        for (int pp = 0; pp < VT; ++pp) acc = fmaf(s_a[pp * KP + k], s_x[pp * CP + c], acc);
+        vacc[j] = acc;
+      }
+    }
+    if (tid < K)
+      for (int pp = 0; pp < VT; ++pp) asum += s_a[pp * KP + tid];
+  }
+  float* dst = a.part + ((size_t)b * a.nsplit + split) * (KC_ + K);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int e = tid + 256 * j;
+    if (j < nown && e < KC_) dst[e] = vacc[j];
+  }
+  if (tid < K) dst[KC_ + tid] = asum;
+}
+
+__global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.C, K = a.K, KC_ = K * C;
+  float* s_v = sm;            // [K*C]
+  float* s_as = s_v + KC_;    // [K]
+  float* s_n = s_as + K;      // [K] row norms, then [4] wave sums
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float* base = a.part + (size_t)b * a.nsplit * (KC_ + K);
+  for (int e = tid; e < KC_ + K; e += 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < a.nsplit; ++sp) s += base[(size_t)sp * (KC_ + K) + e];
+    s_v[e] = s;               // s_as follows s_v contiguously
+  }
+  __syncthreads();
+  for (int e = tid; e < KC_; e += 256) {
+    const int k = e / C, c = e - k * C;
+    s_v[e] = s_v[e] - s_as[k] * a.cent[k * C + c];
+  }
+  __syncthreads();
+  // intra-normalisation: 4 threads per cluster row
+  for (int k = tid >> 2; k < K; k += 64) {
+    const int q = tid & 3, cq = C >> 2;
+    float ss = 0.f;
+    for (int c = q * cq; c < (q + 1) * cq; ++c) { const float v = s_v[k * C + c]; ss = fmaf(v, v, ss); }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    if (q == 0) s_n[k] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+  __syncthreads();
+  float tot = 0.f;
+  for (int e = tid; e < KC_; e += 256) {
+    const float v = s_v[e] * s_n[e / C];
+    s_v[e] = v;
+    tot = fmaf(v, v, tot);
+  }
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  __syncthreads();
+  if ((tid & 63) == 0) s_n[tid >> 6] = tot;
+  __syncthreads();
+  const float inv = 1.f / fmaxf(sqrtf(s_n[0] + s_n[1] + s_n[2] + s_n[3]), 1e-12f);
+  for (int e = tid; e < KC_; e += 256) a.out[(size_t)b * KC_ + e] = s_v[e] * inv;
+}
+
+int launch_netvlad(const VladArgs& a, hipStream_t s) {
+  if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 4096 || a.K < 4) return -1100;
+  const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
+  hipLaunchKernelGGL(netvlad_partial_kernel, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+  const size_t lds2 = (size_t)(a.K * a.C + 2 * a.K + 8) * sizeof(float);
+  hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(256), lds2, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace kp2d

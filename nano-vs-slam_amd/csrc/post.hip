@@ -1,0 +1,260 @@
+// Post-processing and keypoint selection for the kp2dtiny path.
+//
+//  * post_kernel       KP2DTinyV2/V3.post_processing (models/kp2dtiny.py:593-625 / :959-993):
+//                      border mask (:520-528), coordinate decode + clamp (:597-614, grid from
+//                      utils/image.py:44-75), normalize_coord (:642-647), grid_sample(bilinear,
+//                      align_corners=True, zeros) + division by the L2 norm without eps (:627-631).
+//  * seg_argmax_kernel sample_seg (:633-640 / :1001-1008): argmax over classes, int64, H/2 x W/2.
+//  * topk_kernel       the callers' selectors: score > thr, then the k best,
+//                      ordered (score desc, flat index asc) — the order of torch.topk in
+//                      gluefactory/models/extractors/kp2dtiny.py:40; K1/K2 use the same SET.
+// Every float op that feeds an index decision is written with explicit round-to-nearest
+// intrinsics so hipcc's default fp-contraction cannot fuse it differently from the reference.
+#include "kp2d_kernels.h"
+
+namespace kp2d {
+
+template <int C>
+__global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
+  const int Hc = a.Hc, Wc = a.Wc;
+  const int ncell = Hc * Wc;
+  const int cell_id = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (cell_id >= ncell) return;
+  const int yc = cell_id / Wc, xc = cell_id - yc * Wc;
+  const size_t so = (size_t)b * ncell + cell_id;
+
+  const bool border = (yc == 0) | (yc == Hc - 1) | (xc == 0) | (xc == Wc - 1);
+  a.score_out[so] = __fmul_rn(a.score_in[so], border ? 0.f : 1.f);
+
+  const float step = (float)(a.cell - 1) * 0.5f;
+  const float gain = a.cross_ratio * step;
+  const float sx = a.shift[((size_t)b * 2 + 0) * ncell + cell_id];
+  const float sy = a.shift[((size_t)b * 2 + 1) * ncell + cell_id];
+  float cx = __fadd_rn(__fadd_rn(__fmul_rn((float)xc, (float)a.cell), step), __fmul_rn(sx, gain));
+  float cy = __fadd_rn(__fadd_rn(__fmul_rn((float)yc, (float)a.cell), step), __fmul_rn(sy, gain));
+  cx = fminf(fmaxf(cx, 0.f), (float)(a.W - 1));
+  cy = fminf(fmaxf(cy, 0.f), (float)(a.H - 1));
+  a.coord[((size_t)b * 2 + 0) * ncell + cell_id] = cx;
+  a.coord[((size_t)b * 2 + 1) * ncell + cell_id] = cy;
+  if (a.desc == nullptr) return;
+
+  // normalize_coord with the IMAGE size, then grid_sample's un-normalisation with the FEATURE size
+  const float gx = __fsub_rn(__fdiv_rn(cx, (float)(a.W - 1) * 0.5f), 1.f);
+  const float gy = __fsub_rn(__fdiv_rn(cy, (float)(a.H - 1) * 0.5f), 1.f);
+  const int Hf = a.Hf, Wf = a.Wf;
+  const float ix = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(Wf - 1));
+  const float iy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(Hf - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.f), ix);
+  const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.f), iy);
+  const bool vx0 = x0 >= 0 && x0 < Wf, vx1 = x1 >= 0 && x1 < Wf;
+  const bool vy0 = y0 >= 0 && y0 < Hf, vy1 = y1 >= 0 && y1 < Hf;
+  const float w00 = (vx0 && vy0) ? __fmul_rn(wx0, wy0) : 0.f;
+  const float w01 = (vx1 && vy0) ? __fmul_rn(wx1, wy0) : 0.f;
+  const float w10 = (vx0 && vy1) ? __fmul_rn(wx0, wy1) : 0.f;
+  const float w11 = (vx1 && vy1) ? __fmul_rn(wx1, wy1) : 0.f;
+  const int cx0 = min(max(x0, 0), Wf - 1), cx1 = min(max(x1, 0), Wf - 1);
+  const int cy0 = min(max(y0, 0), Hf - 1), cy1 = min(max(y1, 0), Hf - 1);
+  const size_t plane = (size_t)Hf * Wf;
+  const float* f = a.feat + (size_t)b * C * plane;
+  const size_t o00 = (size_t)cy0 * Wf + cx0, o01 = (size_t)cy0 * Wf + cx1;
+  const size_t o10 = (size_t)cy1 * Wf + cx0, o11 = (size_t)cy1 * Wf + cx1;
+  float d[C];
+  float ss = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) {
+    const float* fp = f + c * plane;
+    float v = __fmul_rn(fp[o00], w00);
+    v = __fadd_rn(v, __fmul_rn(fp[o01], w01));
+    v = __fadd_rn(v, __fmul_rn(fp[o10], w10));
+    v = __fadd_rn(v, __fmul_rn(fp[o11], w11));
+    d[c] = v;
+    ss = fmaf(v, v, ss);
+  }
+  const float nrm = sqrtf(ss);   // no eps: models/kp2dtiny.py:629-630
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) a.desc[((size_t)b * C + c) * ncell + cell_id] = __fdiv_rn(d[c], nrm);
+}
+
+int launch_post(const PostArgs& a, hipStream_t s) {
+  const int ncell = a.Hc * a.Wc;
+  dim3 grid((ncell + 255) / 256, a.B);
+  switch (a.C) {
+    case 32: hipLaunchKernelGGL(post_kernel<32>, grid, dim3(256), 0, s, a); break;
+    case 64: hipLaunchKernelGGL(post_kernel<64>, grid, dim3(256), 0, s, a); break;
+    case 128: hipLaunchKernelGGL(post_kernel<128>, grid, dim3(256), 0, s, a); break;
+    default: return -1200;
+  }
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void seg_argmax_kernel(const ArgmaxArgs a) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= (size_t)a.HW) return;
+  const float* sp = a.seg + (size_t)b * a.C * a.HW + p;
+  float best = sp[0];
+  int bi = 0;
+  for (int c = 1; c < a.C; ++c) {
+    const float v = sp[(size_t)c * a.HW];
+    if (v > best) { best = v; bi = c; }   // first maximum wins, as torch.argmax on CPU
+  }
+  a.ids[(size_t)b * a.HW + p] = (int64_t)bi;
+}
+
+int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(seg_argmax_kernel, dim3((a.HW + 255) / 256, a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-k: one workgroup per frame.  Keys are 64-bit (order-preserving score bits << 32 | ~index), so
+// they are unique: an 8-pass MSB radix select finds the count-th largest key exactly, the survivors
+// are compacted into LDS and bitonic-sorted descending -> (score desc, index asc), deterministic.
+// ---------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 4096;
+
+__device__ __forceinline__ unsigned long long topk_key(float s, int idx, float thr) {
+  if (!(s > thr)) return 0ull;
+  unsigned u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
+  // all LDS in the dynamic region (16-byte aligned base): [kpow] keys | prefix | hist[256] | 3 counters
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+  const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
+  const float* sc = a.score + (size_t)b * n;
+  int kpow = 1;
+  while (kpow < a.k) kpow <<= 1;
+  unsigned long long& s_prefix = s_keys[kpow];
+  unsigned* hist = reinterpret_cast<unsigned*>(&s_keys[kpow + 2]);
+  unsigned& s_rank = hist[256];
+  unsigned& s_ncand = hist[257];
+  unsigned& s_fill = hist[258];
+
+  if (tid == 0) s_ncand = 0;
+  __syncthreads();
+  unsigned local = 0;
+  for (int e = tid; e < n; e += 256) local += (sc[e] > a.thr) ? 1u : 0u;
+  atomicAdd(&s_ncand, local);
+  __syncthreads();
+  const unsigned ncand = s_ncand;
+  const unsigned count = min((unsigned)a.k, ncand);
+  if (tid == 0) a.count[b] = (int)count;
+
+  for (int e = tid; e < kpow; e += 256) s_keys[e] = 0ull;
+
+  unsigned long long thresh = ~0ull;   // nothing selected
+  if (count > 0) {
+    if (tid == 0) { s_prefix = 0ull; s_rank = count; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      const int shift = pass * 8;
+      const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
+      for (int e = tid; e < n; e += 256) {
+        const unsigned long long key = topk_key(sc[e], e, a.thr);
+        if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned rank = s_rank, cum = 0;
+        int bin = 255;
+        for (; bin > 0; --bin) {
+          if (cum + hist[bin] >= rank) break;
+          cum += hist[bin];
+        }
+        s_rank = rank - cum;
+        s_prefix = prefix | ((unsigned long long)bin << shift);
+      }
+      __syncthreads();
+    }
+    thresh = s_prefix;   // the count-th largest key
+  }
+  if (tid == 0) s_fill = 0;
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const unsigned long long key = topk_key(sc[e], e, a.thr);
+    if (key != 0ull && key >= thresh) {
+      const unsigned slot = atomicAdd(&s_fill, 1u);
+      if (slot < (unsigned)kpow) s_keys[slot] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= kpow; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (kpow >> 1); t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = s_keys[lo], y = s_keys[hi];
+        if ((x < y) == desc) { s_keys[lo] = y; s_keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < a.k; e += 256) {
+    const unsigned long long key = s_keys[e];
+    const bool ok = (unsigned)e < count;
+    const int idx = ok ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : -1;
+    a.idx[(size_t)b * a.k + e] = idx;
+    if (a.val) a.val[(size_t)b * a.k + e] = ok ? sc[idx] : 0.f;
+  }
+}
+
+int launch_topk(const TopkArgs& a, hipStream_t s) {
+  if (a.k < 1 || a.k > TOPK_MAX || a.n < 1) return -1300;
+  int kpow = 1;
+  while (kpow < a.k) kpow <<= 1;
+  hipLaunchKernelGGL(topk_kernel, dim3(a.B), dim3(256), (size_t)kpow * 8 + 16 + 260 * 4, s, a);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per selected keypoint
+  const int lane = threadIdx.x & 63;
+  if (j >= a.k) return;
+  const int idx = a.idx[(size_t)b * a.k + j];
+  if (lane < 2) a.pts[((size_t)b * a.k + j) * 2 + lane] = idx >= 0 ? a.coord[((size_t)b * 2 + lane) * a.n + idx] : 0.f;
+  for (int c = lane; c < a.C; c += 64)
+    a.dsel[((size_t)b * a.k + j) * a.C + c] = idx >= 0 ? a.desc[((size_t)b * a.C + c) * a.n + idx] : 0.f;
+}
+
+int launch_gather(const GatherArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gather_kernel, dim3((a.k + 3) / 4, a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// NHWC (with channel stride / offset) -> planar NCHW; used for API-facing copies of internal tensors.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, float* out, int C, int HW, int istride,
+                                                           int ioff) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? in[((size_t)b * HW + p) * istride + ioff + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) out[((size_t)b * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, in, out, C, HW,
+                     istride, ioff);
+  return (int)hipGetLastError();
+}
+
+}  // namespace kp2d
