@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of the KP2DTiny-S 240x320 multi-task inference path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+``model(x)`` (backbone + score/loc/descriptor/segmentation/NetVLAD heads) + ``post_processing`` +
+threshold/top-k keypoint selection — all on the device, through the C ABI.  Weak scaling: every rank
+owns ``--batch`` frames (frame-batch sharding); the only collective is the start-up
+weight broadcast.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (3x3-conv implicit GEMM): algorithmic FLOPs / HIP-event time per launch,
+                against the fp32 matrix-core peak (the path is compute-bound in fp32)
+  cpu_baseline  the same workload on the host cores (oracle/torch_port.py, plain torch CPU ops), bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+LAYER_BOUNDARY_MB = {(240, 320): 123.86, (120, 160): 30.96, (480, 640): 495.44}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--config", default="S")
+    ap.add_argument("--v3", action="store_true")
+    ap.add_argument("--n-classes", type=int, default=28)
+    ap.add_argument("--top-k", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def seeded_state_dict(model):
+    from oracle.weights import spread_state_dict
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    return spread_state_dict(shapes)
+
+
+def kernel_profile(model, x, H, W, steps):
+    """Per-launch HIP-event timing inside the engine (events recorded on the launch stream)."""
+    eng = model._engine
+    lib = eng.lib
+    lib.kp2d_set_profiling(eng.handle, 1)
+    agg = {}
+    for _ in range(steps):
+        model(x)
+        n = lib.kp2d_profile_count(eng.handle)
+        layer, kern = C.c_char_p(), C.c_char_p()
+        ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+        for i in range(n):
+            lib.kp2d_profile_get(eng.handle, i, C.byref(layer), C.byref(kern), C.byref(ms), C.byref(fl), C.byref(by))
+            fam = kern.value.decode().split("<")[0]
+            a = agg.setdefault(fam, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            a["ms"] += ms.value
+            a["flops"] += fl.value
+            a["bytes"] += by.value
+            a["launches"] += 1
+    lib.kp2d_set_profiling(eng.handle, 0)
+    return agg
+
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes all host threads in /proc but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args, sd_np):
+    """Host-core timing of the same step (forward + post + selection) on a bounded sample."""
+    from oracle import kp2d_oracle as orc
+    from oracle import torch_port as tp
+    from oracle.weights import synthetic_frames
+    cfg = orc.get_config(args.config, args.v3)
+    p = tp.to_torch(sd_np)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    best, best_b, log = 0.0, 1, []
+    budget = args.cpu_seconds / 2
+    for b in (1, 8):
+        x = torch.from_numpy(synthetic_frames(b, args.height, args.width, seed=7))
+        with torch.no_grad():
+            def step():
+                out = tp.forward(x, p, cfg)
+                post = tp.post_processing(out, args.height, args.width, cfg)
+                return tp.select(post, 0.7, args.top_k)
+            step()
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                step()
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt > budget or n >= 50:
+                    break
+        fps = n * b / dt
+        log.append(f"B={b}: {n} iters, {fps:.1f} frames/s")
+        if fps > best:
+            best, best_b = fps, b
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(best, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"torch-CPU port of the path (oracle/torch_port.py), {args.config} {args.height}x{args.width}, "
+                      f"forward+post+select, best of B in (1,8) = B{best_b}; " + "; ".join(log) + f"; cpu: {model_name}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from nano_vs_slam_amd.selectors import gather_keypoints, select_topk
+    from nano_vs_slam_amd.sharding import broadcast_model_weights
+
+    model = tiny_factory(args.config, args.n_classes, v3=args.v3)
+    sd_np = None
+    if rank == 0:
+        sd_np = seeded_state_dict(model)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    model = model.to(dev).eval()
+    model.training = False
+    if world > 1:
+        broadcast_model_weights(model, dev, src=0)   # the one RCCL collective of the job
+
+    B, H, W = args.batch, args.height, args.width
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = torch.rand(B, 3, H, W, device=dev, generator=g) * 2.0 - 1.0   # synthetic frames generated in HBM
+
+    def step():
+        out = model(x)
+        out = model.post_processing(out, H, W)
+        idx, val, cnt = select_topk(out["score"], args.top_k, 0.7)
+        pts, desc = gather_keypoints(out["coord"], out["feat"], idx)
+        return out, pts, desc, cnt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        fps = frames / dt
+        with torch.no_grad():
+            agg = kernel_profile(model, x, H, W, args.profile_steps)
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        a = agg[dom]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        total_ms = sum(v["ms"] for v in agg.values())
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": a["launches"] // args.profile_steps,
+                "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                "share_of_kernel_time": round(a["ms"] / total_ms, 4),
+                "algorithmic_gb_per_s": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1),
+                "kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 3) for k, v in agg.items()}}
+        lb = LAYER_BOUNDARY_MB.get((H, W))
+        if lb and args.config == "S" and not args.v3:
+            roof["hbm_layer_boundary_frac"] = round(fps / world * lb * 1e6 / (PEAK_HBM_GBS * 1e9), 4)
+        line = {
+            "metric": "frames/sec KP2DTiny-S 240x320 multitask infer",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"KP2DTiny-{args.config}{'-V3' if args.v3 else ''} {H}x{W}, batch {B}/GPU, "
+                                   f"all heads (score/loc/desc/seg/NetVLAD) + post_processing + top-{args.top_k} selection",
+                       "global_batch": world * B, "frame_shards": world, "n_classes": args.n_classes},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, sd_np)
+            line["speedup_vs_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, z
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def golden_inputs(meta):
+    """Regenerate the (weights, frames) a fixture was produced from — nothing but seeds is stored."""
+    from oracle import kp2d_oracle as orc
+    from oracle.weights import spread_state_dict, synthetic_frames
+    cfg = orc.get_config(meta["config"], meta["v3"])
+    shapes = orc.state_dict_shapes(cfg, meta["n_classes"])
+    sd = spread_state_dict(shapes, seed=meta["weight_seed"], head_gain=meta["head_gain"])
+    x = synthetic_frames(meta["B"], meta["H"], meta["W"], meta["frame_seed"], meta["smooth"])
+    return cfg, sd, x
+
+
+def product_model(config, v3, n_classes, device="cuda:0", seed=1234):
+    """The product model (HIP engine) with the seeded spread weights, in inference mode."""
+    import torch
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from oracle.weights import spread_state_dict
+    model = tiny_factory(config, n_classes, v3=v3)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = spread_state_dict(shapes, seed=seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(device).eval()
+    model.training = False
+    return model, sd
+
+
+@pytest.fixture(scope="session")
+def repo_root():
+    return ROOT
+
+
+def assert_topk_equivalent(idx, ref_scores_flat, ref_idx, tol=2e-5):
+    """Two correct fp32 implementations differ by ~1e-6 in score, so an ORDERED top-k list may swap
+    neighbours whose scores are closer than that.  Demand: (1) the same SET, except for cells whose
+    reference score is within ``tol`` of the k-th score; (2) the order is non-increasing in the
+    reference's scores up to ``tol``."""
+    idx = np.asarray(idx).reshape(-1)
+    ref_idx = np.asarray(ref_idx).reshape(-1)
+    valid = idx >= 0
+    assert valid.sum() == (ref_idx >= 0).sum()
+    idx, ref_idx = idx[valid], ref_idx[ref_idx >= 0]
+    assert len(np.unique(idx)) == len(idx)
+    if len(idx) == 0:
+        return
+    kth = ref_scores_flat[ref_idx].min()
+    diff = np.setxor1d(idx, ref_idx)
+    assert np.all(np.abs(ref_scores_flat[diff] - kth) <= tol), "top-k sets differ beyond rounding"
+    s = ref_scores_flat[idx]
+    assert np.all(s[1:] - s[:-1] <= tol), "top-k order is not score-descending"

@@ -1,0 +1,111 @@
+"""Host-side mirror of the reference's model API (no GPU needed)."""
+import numpy as np
+import pytest
+import torch
+
+from nano_vs_slam_amd.kp2dtiny.models import kp2dtiny as K
+from nano_vs_slam_amd.sharding import shard_range
+from oracle import kp2d_oracle as orc
+from oracle.weights import spread_state_dict, synthetic_frames
+
+# measured on the imported reference
+PARAMS = {("S", False, 28): 928079, ("N", False, 28): 528959, ("S_A", False, 28): 968271,
+          ("S", True, 19): 704934, ("S_A", True, 28): 747727}
+
+
+@pytest.mark.parametrize("key", list(PARAMS))
+def test_state_dict_layout_and_param_count(key):
+    name, v3, ncls = key
+    m = K.tiny_factory(name, ncls, v3=v3)
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == list(orc.state_dict_shapes(orc.get_config(name, v3), ncls).items())
+    assert sum(p.numel() for p in m.parameters()) == PARAMS[key]
+    assert m.training is True            # reference force-sets it (kp2dtiny.py:456,813)
+    m.eval()
+    assert m.training is False
+
+
+def test_tests_py_equivalent_construction():
+    """reference tests.py: tiny_factory("S_A", 28, v3=True) builds; attributes callers read exist."""
+    from src.kp2dtiny.models.kp2dtiny import tiny_factory   # the reference's import line
+    m = tiny_factory("S_A", 28, v3=True)
+    assert (m.nfeatures, m.nClasses, m.cell, m.global_desc_dim) == (32, 28, 4, 4096)
+    assert m.get_global_desc_dim() == m.get_netvlad_dim() == 4096 and m.get_num_clusters() == 64
+    info = m.gather_info()
+    assert info["total_params"] == 747727 and info["netvlad_dim"] == 4096
+    m.device = "cuda"                      # callers assign it (eval_multitask.py:197-198)
+    m.freeze_backbone()
+    assert not any(p.requires_grad for p in m.backbone.parameters())
+    m.freeze_segmentation(except_last_layer=True)
+    assert all(p.requires_grad for p in m.seg_head.convs[-1].parameters())
+
+
+def test_get_config_contract():
+    with pytest.raises(ValueError):
+        K.get_config("nope")
+    with pytest.raises(ValueError):
+        K.get_config("F", v3=True)
+    a = K.get_config("S", to_mcu=True)
+    assert a["upscale_method"] == "convtranspose" and a["leaky_relu"] is False
+    # the reference leaks that mutation into later calls (App. B.20); this build returns copies
+    assert "upscale_method" not in K.get_config("S")
+    assert K.get_config("N")["num_clusters"] == 32 and "num_clusters" not in K.get_config("N", v3=True)
+    assert set(K.KP2DTINY_CONFIGS) == {"S", "S_A", "N", "N_A", "D", "F", "GEM_N", "GEM_S_A", "CONVAP_S_A"}
+    assert set(K.KP2DTINYV3_CONFIGS) == {"S", "S_A", "N", "N_A", "D", "D_A", "CONVAP_S_A"}
+
+
+def test_partial_and_strict_loads():
+    m = K.tiny_factory("S", 28)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in
+          spread_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}).items()}
+    m.load_state_dict(sd, strict=True)
+    # callers surgically drop the class layer (train_multitask.py:309-325) and load non-strict
+    part = {k: v for k, v in sd.items() if not k.startswith("seg_head.convs.8")}
+    res = m.load_state_dict(part, strict=False)
+    assert sorted(res.missing_keys) == ["seg_head.convs.8.bias", "seg_head.convs.8.weight"]
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(part, strict=True)
+
+
+def test_no_cpu_path():
+    m = K.tiny_factory("S", 28).eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError):
+        m.post_processing({"score": torch.zeros(1, 1, 8, 8), "coord": torch.zeros(1, 2, 8, 8),
+                           "feat": torch.zeros(1, 32, 16, 16), "seg": torch.zeros(1, 28, 16, 16)}, 32, 32)
+    with pytest.raises(RuntimeError):
+        m.backbone(torch.zeros(1, 3, 32, 32))      # parameter holders never execute torch ops
+
+
+def test_unbuilt_variants_raise_not_fallback():
+    for kw in (dict(to_mcu=True), dict(to_export=True)):
+        m = K.tiny_factory("S", 28, **kw)
+        with pytest.raises(NotImplementedError):
+            m._check_built()
+    with pytest.raises(NotImplementedError):
+        K.KP2DTinyV2(**K.get_config("GEM_N"), nClasses=28)._check_built()
+    with pytest.raises(NotImplementedError):
+        K.KP2DTinyV2(**K.get_config("S"), nClasses=28, depth=True)._check_built()
+
+
+def test_shard_range_partitions_frames():
+    for n in (1, 7, 64, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
+
+
+def test_seeded_inputs_are_reproducible():
+    a = spread_state_dict({"backbone.conv1a.conv.weight": (16, 3, 3, 3), "backbone.conv1a.bn.running_var": (16,)})
+    b = spread_state_dict({"backbone.conv1a.bn.running_var": (16,), "backbone.conv1a.conv.weight": (16, 3, 3, 3)})
+    assert all(np.array_equal(a[k], b[k]) for k in a)       # independent of enumeration order
+    assert a["backbone.conv1a.bn.running_var"].min() >= 0.5
+    x = synthetic_frames(2, 16, 24, seed=7)
+    assert x.shape == (2, 3, 16, 24) and x.dtype == np.float32 and -1 <= x.min() and x.max() <= 1
+    assert np.array_equal(x, synthetic_frames(2, 16, 24, seed=7))
