@@ -39,11 +39,12 @@ __device__ __forceinline__ float act_apply(float v, int act, int ch) {
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case ACT_TANH: return tanhf(v);
     case ACT_SIGMOID0_TANH: return ch == 0 ? 1.f / (1.f + expf(-v)) : tanhf(v);
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     default: return v;
   }
 }
 
-template <int KC, int NT>
+template <int KC, int NT, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KCP = KC + 4;
@@ -81,6 +82,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   const int b_base = i * KCP + h * KH;
 
   const int nchunk = (a.cin + KC - 1) / KC;
+  const float* src0 = a.in0.p + (size_t)b * a.in0.bs + a.in0.o;
+  const float* src1 = a.in1.p + (size_t)b * a.in1.bs + a.in1.o;
+  const int c0 = a.in0.c;
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();
     for (int g = tid; g < IN_ROWS * IN_ROWS * Q; g += 256) {
@@ -90,22 +94,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
       const int c = ch * KC + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin) {
-        const size_t pix = ((size_t)b * H + gy) * W + gx;
-        const float* src = (c < a.c0) ? a.in0 + pix * a.s0 + a.o0 + c : a.in1 + pix * a.s1 + a.o1 + (c - a.c0);
+        const float* src = (c < c0) ? src0 + gy * a.in0.rs + gx * a.in0.ps + c
+                                    : src1 + gy * a.in1.rs + gx * a.in1.ps + (c - c0);
         v = *reinterpret_cast<const float4*>(src);
       }
       *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
     }
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * 9 * N * KC);
-    for (int g = tid; g < 9 * N * Q; g += 256) {
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
+    for (int g = tid; g < TAPS * N * Q; g += 256) {
       const int row = g / Q, q = g - row * Q;
       *reinterpret_cast<float4*>(&s_w[row * KCP + 4 * q]) = wsrc[g];
     }
     __syncthreads();
 
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 1, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 1;
       float av[2][KH], bv[NT][KH];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -231,15 +235,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   }
 }
 
-template <int KC, int NT>
+template <int KC, int NT, int TAPS>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
   constexpr int KCP = KC + 4;
-  size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + 9 * NT * 32 * KCP) * sizeof(float);
+  size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + TAPS * NT * 32 * KCP) * sizeof(float);
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
@@ -247,7 +251,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
   if (a.store == ST_NCHW && groups != 1) return -1002;  // planar outputs are <= 64 channels
-  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT>), dim3(grid, groups), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS>), dim3(grid, groups), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -255,8 +259,13 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   // npad is 32, or a multiple of 64 handled as npad/64 channel groups (blockIdx.y)
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32;
-  if (kc == 16) return one ? launch_t<16, 1>(a, s) : launch_t<16, 2>(a, s);
-  if (kc == 8) return one ? launch_t<8, 1>(a, s) : launch_t<8, 2>(a, s);
+  if (a.taps == 9) {
+    if (kc == 16) return one ? launch_t<16, 1, 9>(a, s) : launch_t<16, 2, 9>(a, s);
+    if (kc == 8) return one ? launch_t<8, 1, 9>(a, s) : launch_t<8, 2, 9>(a, s);
+  } else if (a.taps == 1) {
+    if (kc == 16) return one ? launch_t<16, 1, 1>(a, s) : launch_t<16, 2, 1>(a, s);
+    if (kc == 8) return one ? launch_t<8, 1, 1>(a, s) : launch_t<8, 2, 1>(a, s);
+  }
   return -1000;
 }
 

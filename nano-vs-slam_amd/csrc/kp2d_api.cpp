@@ -56,10 +56,15 @@ struct ConvPack {
   std::string name;     // state-dict prefix, e.g. "backbone.conv2a"
   bool bn = false;      // AnnotatedConvBnReLUModel (conv.weight + bn.*) vs plain Conv2d (weight + bias)
   bool shuffle = false; // rows permuted for the PixelShuffle-folding store
-  int cin = 0, cout = 0, npad = 0, kc = 16;
+  bool bias = true;     // plain conv only: has a .bias tensor
+  int kind = 0;         // 0: 3x3 [co][ci][3][3]   1: 1x1 [co][ci][1][1]   2: 2x2 stride 2 [co][ci][2][2] as 1x1 over 4*ci
+  int taps = 9;
+  int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
-  size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * 9 * npad * kc; }
+  size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
 };
+
+struct VecPack { size_t off = 0; int n = 0; };   // small per-channel vectors (LayerNorm g/b, depthwise w/b)
 
 struct ProfRec {
   std::string layer, kernel;
@@ -120,6 +125,7 @@ struct kp2d_model {
   std::map<std::string, int> conv_index;
   size_t conv1a_w = 0, conv1a_sc = 0, conv1a_sh = 0;
   size_t vlad_wa = 0, vlad_cent = 0;
+  std::map<std::string, VecPack> vecs;
   size_t blob_floats = 0;
   float* blob = nullptr;
   bool finalized = false;
@@ -161,6 +167,41 @@ void add_conv(kp2d_model* m, const std::string& p, int ci, int co, bool shuffle 
   m->convs.push_back(c);
 }
 
+// 1x1 conv (kind 1) or 2x2 stride-2 conv (kind 2) routed through the MFMA conv kernel with taps = 1
+void add_pw(kp2d_model* m, const std::string& p, int ci, int co, bool bias, int kind) {
+  const int k = kind == 2 ? 2 : 1;
+  add_spec(m, p + ".weight", {co, ci, k, k});
+  if (bias) add_spec(m, p + ".bias", {co});
+  ConvPack c;
+  c.name = p; c.bn = false; c.bias = bias; c.kind = kind; c.taps = 1;
+  c.cin = kind == 2 ? 4 * ci : ci; c.cout = co;
+  m->conv_index[p] = (int)m->convs.size();
+  m->convs.push_back(c);
+}
+
+// SegFormerAttentionModule(c) (modules/segformer.py:209-220); PreNorm registers fn before norm
+void add_attention_module(kp2d_model* m, const std::string& p, int c) {
+  add_pw(m, p + ".att.fn.to_q", c, c, false, 1);
+  add_pw(m, p + ".att.fn.to_kv", c, 2 * c, false, 2);
+  add_pw(m, p + ".att.fn.to_out", c, c, false, 1);
+  add_spec(m, p + ".att.norm.g", {1, c, 1, 1});
+  add_spec(m, p + ".att.norm.b", {1, c, 1, 1});
+  const int h = 2 * c;
+  add_pw(m, p + ".mff.fn.net.0", c, h, true, 1);
+  add_spec(m, p + ".mff.fn.net.1.net.0.weight", {h, 1, 3, 3});
+  add_spec(m, p + ".mff.fn.net.1.net.0.bias", {h});
+  add_pw(m, p + ".mff.fn.net.1.net.1", h, h, true, 1);
+  add_pw(m, p + ".mff.fn.net.3", h, c, true, 1);
+  add_spec(m, p + ".mff.norm.g", {1, c, 1, 1});
+  add_spec(m, p + ".mff.norm.b", {1, c, 1, 1});
+  m->vecs[p + ".att.norm.g"].n = c;
+  m->vecs[p + ".att.norm.b"].n = c;
+  m->vecs[p + ".mff.norm.g"].n = c;
+  m->vecs[p + ".mff.norm.b"].n = c;
+  m->vecs[p + ".mff.fn.net.1.net.0.weight"].n = 9 * h;   // repacked [9][h]
+  m->vecs[p + ".mff.fn.net.1.net.0.bias"].n = h;
+}
+
 int describe(kp2d_model* m) {
   const kp2d_config& g = m->cfg;
   const int c1 = m->c1, c2 = m->c2, c3 = m->c3, c4 = m->c4, c5 = m->c5, d1 = m->d1;
@@ -194,7 +235,15 @@ int describe(kp2d_model* m) {
   const int ch = c5, cexp = c4 + c3;
   const int last_in = v3 ? ch / 2 : ch;
   if (g.use_attention) {
-    return fail(KP2D_ERR_UNSUPPORTED, "use_attention=1: the efficient-self-attention seg head is not built yet");
+    if (ch > 64 || (ch % 16)) return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 64, multiple of 16)", ch);
+    add_cbr(m, "seg_head.convs.0", c4, ch);
+    add_attention_module(m, "seg_head.convs.1", ch);
+    add_attention_module(m, "seg_head.convs.2", ch);
+    add_cbr(m, "seg_head.convs.3", ch, d1, true);
+    add_cbr(m, "seg_head.convs.4", ch + d1 / 4, ch);
+    add_cbr(m, "seg_head.convs.5", ch, d1, true);
+    add_cbr(m, "seg_head.convs.6", cexp, ch);
+    add_conv(m, "seg_head.convs.7", last_in, g.n_classes);
   } else {
     add_cbr(m, "seg_head.convs.0", c4, ch);
     add_cbr(m, "seg_head.convs.1", ch, ch);
@@ -228,6 +277,7 @@ int describe(kp2d_model* m) {
     c.sc_off = take(c.npad);
     c.sh_off = take(c.npad);
   }
+  for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
   m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
   m->vlad_cent = take((size_t)g.num_clusters * g.encoder_dim);
   m->blob_floats = off;
@@ -264,13 +314,13 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
     bn_fold(m, "backbone.conv1a.bn", c1, &blob[m->conv1a_sc], &blob[m->conv1a_sh]);
   }
   for (const auto& c : m->convs) {
-    const auto& w = *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][cin][3][3]
+    const auto& w = *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][ci][k][k]
     std::vector<float> sc(c.cout), sh(c.cout);
     if (c.bn) {
       bn_fold(m, c.name + ".bn", c.cout, sc.data(), sh.data());
     } else {
-      const auto& b = *host_get(m, c.name + ".bias");
-      for (int i = 0; i < c.cout; ++i) { sc[i] = 1.f; sh[i] = b[i]; }
+      const std::vector<float>* b = c.bias ? host_get(m, c.name + ".bias") : nullptr;
+      for (int i = 0; i < c.cout; ++i) { sc[i] = 1.f; sh[i] = b ? (*b)[i] : 0.f; }
     }
     const int ng = c.npad <= 32 ? 32 : 64;          // channels per workgroup group
     const int ngroups = c.npad / ng;
@@ -286,13 +336,35 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
       const int grp = q / ng, n = q % ng;
       for (int ci = 0; ci < c.cin; ++ci) {
         const int chk = ci / c.kc, kk = ci % c.kc;
-        for (int tap = 0; tap < 9; ++tap) {
-          const size_t dst = c.w_off + ((((size_t)grp * nchunk + chk) * 9 + tap) * ng + n) * c.kc + kk;
-          blob[dst] = w[((size_t)co * c.cin + ci) * 9 + tap];
+        if (c.kind == 0) {
+          for (int tap = 0; tap < 9; ++tap) {
+            const size_t dst = c.w_off + ((((size_t)grp * nchunk + chk) * 9 + tap) * ng + n) * c.kc + kk;
+            blob[dst] = w[((size_t)co * c.cin + ci) * 9 + tap];
+          }
+        } else {
+          const size_t dst = c.w_off + (((size_t)grp * nchunk + chk) * ng + n) * c.kc + kk;
+          if (c.kind == 1) {
+            blob[dst] = w[(size_t)co * c.cin + ci];
+          } else {
+            // GEMM k = dy*2C + dx*C + cc  <-  weight[co][cc][dy][dx]   (C = cin/4)
+            const int Cq = c.cin / 4, dy = ci / (2 * Cq), dx = (ci / Cq) & 1, cc = ci % Cq;
+            blob[dst] = w[(((size_t)co * Cq + cc) * 2 + dy) * 2 + dx];
+          }
         }
       }
     }
     (void)ngroups;
+  }
+  for (const auto& kv : m->vecs) {
+    const auto& src = *host_get(m, kv.first);
+    const std::string& key = kv.first;
+    if (key.size() > 13 && key.compare(key.size() - 13, 13, ".net.0.weight") == 0 && key.find(".net.1.") != std::string::npos) {
+      const int h = kv.second.n / 9;                       // depthwise [h][1][3][3] -> [9][h]
+      for (int c = 0; c < h; ++c)
+        for (int t = 0; t < 9; ++t) blob[kv.second.off + (size_t)t * h + c] = src[(size_t)c * 9 + t];
+    } else {
+      std::copy(src.begin(), src.end(), blob.begin() + kv.second.off);
+    }
   }
   const auto& wa = *host_get(m, "vlad_head.netvlad.conv.weight");
   const auto& ce = *host_get(m, "vlad_head.netvlad.centroids");
@@ -328,17 +400,17 @@ struct Plan {
     if (!m->profiling || dry) return;
     if (m->prof_used == m->prof.size()) {
       ProfRec r;
-      hipEventCreate(&r.e0);
-      hipEventCreate(&r.e1);
+      (void)hipEventCreate(&r.e0);
+      (void)hipEventCreate(&r.e1);
       m->prof.push_back(r);
     }
     ProfRec& r = m->prof[m->prof_used];
     r.layer = layer; r.kernel = kernel; r.flops = flops; r.bytes = bytes;
-    hipEventRecord(r.e0, stream);
+    (void)hipEventRecord(r.e0, stream);
   }
   void prof_end() {
     if (!m->profiling || dry) return;
-    hipEventRecord(m->prof[m->prof_used].e1, stream);
+    (void)hipEventRecord(m->prof[m->prof_used].e1, stream);
     ++m->prof_used;
   }
   void check(int e, const char* what) {
@@ -346,27 +418,110 @@ struct Plan {
                                            e > 0 ? hipGetErrorString((hipError_t)e) : "unsupported shape");
   }
 
-  // generic 3x3 conv: in1 may be null (no concat).  Channel slices via (c, off).
-  void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
-            float* out0, int os0, int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
-    if (rc != KP2D_OK) return;
+  static ConvSrc dense(const float* p, const Act& t, int c, int o) {
+    ConvSrc s{};
+    s.p = p; s.c = c; s.o = o;
+    s.ps = t.C; s.rs = (long)t.W * t.C; s.bs = (long)t.H * t.W * t.C;
+    return s;
+  }
+  // core launch: sources already described
+  void conv_src(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
+                int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
+    if (rc != KP2D_OK || dry) return;
     const ConvPack& c = m->convs[m->conv_index.at(name)];
-    if (dry) return;
     ConvArgs a{};
-    a.in0 = ptr(in0); a.c0 = c0; a.s0 = in0.C; a.o0 = o0;
-    if (in1) { a.in1 = ptr(*in1); a.c1 = in1->C; a.s1 = in1->C; a.o1 = 0; }
-    else { a.in1 = a.in0; a.c1 = 0; a.s1 = in0.C; a.o1 = 0; }
+    a.in0 = s0; a.in1 = s1; a.taps = c.taps;
     a.w = m->blob + c.w_off; a.scale = m->blob + c.sc_off; a.shift = m->blob + c.sh_off;
     a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
     a.B = B; a.H = Hc; a.W = Wc; a.cin = c.cin; a.cout = c.cout; a.npad = c.npad;
     a.act = act; a.store = store; a.nsplit = nsplit;
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
-    if (a.c0 + a.c1 != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), a.c0 + a.c1, c.cin); return; }
+    if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
-    prof_begin(name, c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>", 2.0 * 9 * c.cin * c.cout * px,
-               4.0 * px * (c.cin + c.cout) + 4.0 * 9 * c.cin * c.cout);
+    const char* fam = c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32";
+    prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
     check(launch_conv3x3(a, c.kc, stream), name.c_str());
     prof_end();
+  }
+  // generic conv over dense NHWC activations: in1 may be null (no concat).  Channel slices via (c0, o0).
+  void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
+            float* out0, int os0, int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
+    if (rc != KP2D_OK || dry) return;
+    ConvSrc s0 = dense(ptr(in0), in0, c0, o0);
+    ConvSrc s1 = in1 ? dense(ptr(*in1), *in1, in1->C, 0) : dense(ptr(in0), in0, 0, 0);
+    conv_src(name, s0, s1, act, store, out0, os0, oo0, out1, os1, oo1, nsplit, Hc, Wc);
+  }
+  // 1x1 conv -> NHWC activation
+  Act pw(const std::string& name, const Act& in, int act, int store = ST_NHWC) {
+    const ConvPack& c = m->convs[m->conv_index.at(name)];
+    Act out{};
+    if (store == ST_NHWC_POOL) {
+      out = alloc(c.cout, in.H / 2, in.W / 2);
+      conv(name, in, in.C, 0, nullptr, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, in.H, in.W);
+    } else {
+      out = alloc(c.cout, in.H, in.W);
+      conv(name, in, in.C, 0, nullptr, act, ST_NHWC, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, in.H, in.W);
+    }
+    return out;
+  }
+  Act layernorm(const std::string& prefix, const Act& in) {
+    Act out = alloc(in.C, in.H, in.W);
+    if (rc != KP2D_OK || dry) return out;
+    LnArgs a{ptr(in), m->blob + m->vecs.at(prefix + ".g").off, m->blob + m->vecs.at(prefix + ".b").off, ptr(out),
+             (long)B * in.H * in.W, in.C};
+    const double px = (double)B * in.H * in.W;
+    prof_begin(prefix, "channel_layernorm", 8.0 * px * in.C, 8.0 * px * in.C);
+    check(launch_channel_layernorm(a, stream), prefix.c_str());
+    prof_end();
+    return out;
+  }
+  // SegFormerAttentionModule.forward (modules/segformer.py:217-220); `pool` folds the following MaxPool2d(2,2)
+  Act attention_module(const std::string& p, const Act& x, bool pool) {
+    const int C = x.C, h = x.H, w = x.W;
+    Act ln1 = layernorm(p + ".att.norm", x);
+    Act q = pw(p + ".att.fn.to_q", ln1, ACT_NONE);
+    Act kv = alloc(2 * C, h / 2, w / 2);
+    if (rc == KP2D_OK && !dry) {
+      // 2x2 stride-2 conv == 1x1 conv over [row 2Y | row 2Y+1], each row-view a 2C-channel "pixel" (x, x+1)
+      ConvSrc s0{};
+      s0.p = ptr(ln1); s0.c = 2 * C; s0.o = 0; s0.ps = 2 * C; s0.rs = 2L * w * C; s0.bs = (long)h * w * C;
+      ConvSrc s1 = s0;
+      s1.p = ptr(ln1) + (long)w * C;
+      conv_src(p + ".att.fn.to_kv", s0, s1, ACT_NONE, ST_NHWC, ptr(kv), 2 * C, 0, nullptr, 0, 0, 0, h / 2, w / 2);
+    }
+    release(ln1);
+    Act ao = alloc(C, h, w);
+    if (rc == KP2D_OK && !dry) {
+      const int heads = 4;
+      AttnArgs a{ptr(q), ptr(kv), ptr(ao), B, h * w, (h / 2) * (w / 2), C, heads, 1.0f / std::sqrt((float)(C / heads))};
+      const double st = (double)B * h * w * (h / 2) * (w / 2);
+      prof_begin(p + ".att.fn", "attention", 4.0 * st * C, 4.0 * B * ((double)2 * h * w * C + (h / 2) * (w / 2) * 2.0 * C));
+      check(launch_attention(a, stream), (p + ".att.fn").c_str());
+      prof_end();
+    }
+    release(q);
+    release(kv);
+    Act t = pw(p + ".att.fn.to_out", ao, ACT_NONE);
+    release(ao);
+    Act ln2 = layernorm(p + ".mff.norm", t);
+    release(t);
+    Act f0 = pw(p + ".mff.fn.net.0", ln2, ACT_NONE);
+    release(ln2);
+    Act f1 = alloc(f0.C, h, w);
+    if (rc == KP2D_OK && !dry) {
+      DwArgs a{ptr(f0), m->blob + m->vecs.at(p + ".mff.fn.net.1.net.0.weight").off,
+               m->blob + m->vecs.at(p + ".mff.fn.net.1.net.0.bias").off, ptr(f1), B, h, w, f0.C};
+      const double px = (double)B * h * w;
+      prof_begin(p + ".mff.fn.net.1.net.0", "dwconv3x3", 18.0 * px * f0.C, 8.0 * px * f0.C);
+      check(launch_dwconv3x3(a, stream), (p + ".mff.dw").c_str());
+      prof_end();
+    }
+    release(f0);
+    Act f2 = pw(p + ".mff.fn.net.1.net.1", f1, ACT_GELU);
+    release(f1);
+    Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC);
+    release(f2);
+    return f3;
   }
   // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
   Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr) {
@@ -458,31 +613,49 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(d3);
   }
 
-  // ---- segmentation head (segmentation.py:126-157 V2 / :321-347 V3) ----
+  // ---- segmentation head: segmentation.py:126-157 (V2), :321-347 (V3), :442-466 (V2 att), :588-619 (V3 att) ----
   {
-    Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
-    Act g1 = P.cbr("seg_head.convs.1", g0, nullptr, ST_NHWC_POOL);
-    P.release(g0);
-    Act g2 = P.cbr("seg_head.convs.2", g1, nullptr, ST_NHWC);
-    P.release(g1);
-    Act g3 = P.cbr("seg_head.convs.3", g2, nullptr, ST_NHWC);
-    P.release(g2);
-    Act g4 = P.cbr("seg_head.convs.4", g3, nullptr, ST_SHUFFLE);
-    P.release(g3);
-    Act g5 = P.cbr("seg_head.convs.5", g4, &xb, ST_NHWC);
-    P.release(g4);
-    Act g6 = P.cbr("seg_head.convs.6", g5, nullptr, ST_SHUFFLE);
+    Act g5{};
+    int i;   // index of the CBR(c_exp -> c_hidden) layer
+    if (g.use_attention) {
+      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
+      Act a1 = P.attention_module("seg_head.convs.1", g0, /*pool=*/true);
+      P.release(g0);
+      Act a2 = P.attention_module("seg_head.convs.2", a1, false);
+      P.release(a1);
+      Act g4 = P.cbr("seg_head.convs.3", a2, nullptr, ST_SHUFFLE);
+      P.release(a2);
+      g5 = P.cbr("seg_head.convs.4", g4, &xb, ST_NHWC);
+      P.release(g4);
+      i = 5;
+    } else {
+      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
+      Act g1 = P.cbr("seg_head.convs.1", g0, nullptr, ST_NHWC_POOL);
+      P.release(g0);
+      Act g2 = P.cbr("seg_head.convs.2", g1, nullptr, ST_NHWC);
+      P.release(g1);
+      Act g3 = P.cbr("seg_head.convs.3", g2, nullptr, ST_NHWC);
+      P.release(g2);
+      Act g4 = P.cbr("seg_head.convs.4", g3, nullptr, ST_SHUFFLE);
+      P.release(g3);
+      g5 = P.cbr("seg_head.convs.5", g4, &xb, ST_NHWC);
+      P.release(g4);
+      i = 6;
+    }
+    const std::string L = "seg_head.convs.";
+    Act g6 = P.cbr(L + std::to_string(i), g5, nullptr, ST_SHUFFLE);
     P.release(g5);
-    Act g7 = P.cbr("seg_head.convs.7", g6, &skip, ST_NHWC);
+    Act g7 = P.cbr(L + std::to_string(i + 1), g6, &skip, ST_NHWC);
     P.release(g6);
+    const std::string last = L + std::to_string(i + 2);
     if (v3) {
       const int half = g7.C / 2;   // dim_split = c_hidden // 2 (segmentation.py:190, :339-343)
       P.conv("seg_head.featB", g7, half, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
       const bool sm = (flags & KP2D_FWD_EVAL) && !g.remove_softmax;
-      P.conv("seg_head.convs.8", g7, half, g7.C - half, nullptr, sm ? ACT_SOFTMAX_C : ACT_NONE, ST_NCHW, o.seg, 0, 0,
-             nullptr, 0, 0, g.n_classes, H2, W2);
+      P.conv(last, g7, half, g7.C - half, nullptr, sm ? ACT_SOFTMAX_C : ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0,
+             g.n_classes, H2, W2);
     } else {
-      P.conv("seg_head.convs.8", g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
+      P.conv(last, g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
     }
     P.release(g7);
   }
@@ -571,8 +744,8 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
 
 void kp2d_destroy(kp2d_model* m) {
   if (!m) return;
-  if (m->blob) hipFree(m->blob);
-  for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  if (m->blob) (void)hipFree(m->blob);
+  for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   delete m;
 }
 

@@ -15,6 +15,7 @@ enum Act : int {
   ACT_TANH = 4,            // loc head              models/kp2dtiny.py:575
   ACT_SIGMOID0_TANH = 5,   // V3 fused score/loc: ch0 sigmoid, ch1..2 tanh  models/kp2dtiny.py:927-935
   ACT_SOFTMAX_C = 6,       // V3 eval: Softmax2d over classes                models/kp2dtiny.py:942-943
+  ACT_GELU = 7,            // exact-erf GELU inside MixFeedForward           modules/segformer.py:185
 };
 
 enum Store : int {
@@ -25,12 +26,15 @@ enum Store : int {
   ST_NCHW = 4,             // API-facing planar output; channels [0,nsplit) -> out0, [nsplit,cout) -> out1
 };
 
-// One 3x3 / stride 1 / pad 1 convolution over an NHWC activation that may be the channel-concat
-// of two tensors (torch.cat([up, skip], 1): heads.py:99, segmentation.py:141,149).
+// One 3x3 / stride 1 / pad 1 (taps = 9) or 1x1 (taps = 1) convolution over an NHWC activation that may be
+// the channel-concat of two tensors (torch.cat([up, skip], 1): heads.py:99, segmentation.py:141,149).
+// A source is addressed as ptr + b*bs + y*rs + x*ps + o + c, so strided views work too: the 2x2 stride-2
+// to_kv conv (modules/segformer.py:93-95) is a 1x1 conv over two row-views of the full-resolution tensor.
+struct ConvSrc { const float* p; int c, o; long bs, rs, ps; };   // channels taken, first channel, strides (floats)
 struct ConvArgs {
-  const float* in0; int c0, s0, o0;   // channels taken, pixel stride (floats), first channel
-  const float* in1; int c1, s1, o1;
-  const float* w;                     // packed [cin_pad/KC][9][npad][KC]
+  ConvSrc in0, in1;
+  int taps;                           // 9 or 1
+  const float* w;                     // packed [group][cin_pad/KC][taps][ng][KC]
   const float* scale;                 // [npad]  BN: gamma/sqrt(var+eps); bias conv: 1
   const float* shift;                 // [npad]  BN: beta - mean*scale;   bias conv: bias
   float* out0; int os0, oo0;
@@ -95,6 +99,22 @@ struct GatherArgs {     // gather coords / descriptors of selected cells into [B
   float* pts; float* dsel; int B, C, n, k;
 };
 int launch_gather(const GatherArgs& a, hipStream_t s);
+
+// ---- SegFormerAttentionModule pieces (modules/segformer.py:63-220) ---------------------------
+struct LnArgs { const float* x; const float* g; const float* b; float* y; long npix; int C; };
+int launch_channel_layernorm(const LnArgs& a, hipStream_t s);
+
+struct DwArgs { const float* x; const float* w; const float* bias; float* y; int B, H, W, C; };   // w: [9][C]
+int launch_dwconv3x3(const DwArgs& a, hipStream_t s);
+
+struct AttnArgs {
+  const float* q;      // [B][S][C]   (to_q output, NHWC)
+  const float* kv;     // [B][T][2C]  (to_kv output: k = channels [0,C), v = [C,2C))
+  float* out;          // [B][S][C]
+  int B, S, T, C, heads;
+  float scale;         // (C/heads)^-0.5
+};
+int launch_attention(const AttnArgs& a, hipStream_t s);
 
 // ---- small layout / elementwise kernels -----------------------------------------------------
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s);
