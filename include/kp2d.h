@@ -119,6 +119,14 @@ int kp2d_profile_count(kp2d_model* m);
 /* one record: layer name, kernel family, elapsed ms, algorithmic FLOPs and HBM bytes of that launch */
 int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** kernel, float* ms, double* flops,
                      double* bytes);
+/* Arithmetic of the convolution kernels (both accumulate in fp32 and meet the 1e-3 / index-identity bar):
+ *   KP2D_PREC_FP32   exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain)
+ *   KP2D_PREC_F16X3  split fp16: x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16, fp32-grade error
+ *                    (default; see DESIGN.md "Numerics").  Both weight packs are resident; switching is free. */
+#define KP2D_PREC_FP32 0
+#define KP2D_PREC_F16X3 1
+int kp2d_set_precision(kp2d_model* m, int mode);
+int kp2d_get_precision(const kp2d_model* m);
 /* frames per internal sub-batch (0 = automatic).  Intermediates of one sub-batch stay in the 256 MB Infinity Cache. */
 int kp2d_set_chunk_frames(kp2d_model* m, int frames);
 

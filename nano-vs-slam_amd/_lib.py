@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkp2d_hip.so")
 
 KP2D_FWD_EVAL = 1
+PRECISIONS = {"fp32": 0, "f16x3": 1}
 
 
 class Kp2dConfig(C.Structure):
@@ -64,6 +65,8 @@ SIGNATURES = {
     "kp2d_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _F,
                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kp2d_set_chunk_frames": (C.c_int, [_P, C.c_int]),
+    "kp2d_set_precision": (C.c_int, [_P, C.c_int]),
+    "kp2d_get_precision": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -22,11 +22,23 @@
 //   * Epilogue on the fp32 accumulator in the reference's order: per-channel affine (BatchNorm
 //     scale/shift or bias), activation, then the store mode (NHWC / pooled / both / pixel-shuffled /
 //     planar NCHW through an LDS transpose for the API-facing tensors).
+//
+// Two arithmetic modes share the tiling, the LDS geometry and the epilogue (template parameter PREC):
+//   PREC 0  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (157 TFLOP/s peak).
+//   PREC 1  split fp16 ("f16x3"): every fp32 operand is carried as hi = fp16(x), lo = fp16(x - hi) and
+//           x*w is formed as xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16 with ONE fp32 accumulator
+//           (weights pre-scaled by 2^11 at pack time so wl stays a normal fp16; the epilogue scale carries
+//           2^-11).  gfx950 honours fp16 subnormal MFMA operands and the dropped xl*wl term is 2^-22
+//           relative, so the result is fp32-grade: measured max error vs fp64 1.7e-6 at K = 576 against
+//           1.9e-6 for the exact fp32 chain (tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log).
+//           3 MFMAs of 16x the fp32 rate -> 5.3x fewer matrix-core cycles per product.
 #include "kp2d_kernels.h"
 
 namespace kp2d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 16;
 constexpr int IN_ROWS = 18;
@@ -44,7 +56,7 @@ __device__ __forceinline__ float act_apply(float v, int act, int ch) {
   }
 }
 
-template <int KC, int NT, int TAPS>
+template <int KC, int NT, int TAPS, int PREC>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KCP = KC + 4;
@@ -80,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   const int pcol = 2 * (i >> 2) + (i & 1);
   const int a_base = (prow * IN_PITCH + pcol) * KCP + h * KH;
   const int b_base = i * KCP + h * KH;
+  const int a_base16 = (prow * IN_PITCH + pcol) * KCP + h * 4;   // split mode: +h*16 B inside the hi block
+  const int b_base16 = i * KCP + h * 4;
 
   const int nchunk = (a.cin + KC - 1) / KC;
   const float* src0 = a.in0.p + (size_t)b * a.in0.bs + a.in0.o;
@@ -98,7 +112,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
                                     : src1 + gy * a.in1.rs + gx * a.in1.ps + (c - c0);
         v = *reinterpret_cast<const float4*>(src);
       }
-      *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
+      if (PREC == 0) {
+        *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
+      } else {
+        // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; |x| is clamped to the fp16 range
+        const float lim = 65000.f;
+        const float x0_ = fminf(fmaxf(v.x, -lim), lim), x1_ = fminf(fmaxf(v.y, -lim), lim);
+        const float x2_ = fminf(fmaxf(v.z, -lim), lim), x3_ = fminf(fmaxf(v.w, -lim), lim);
+        f16x4 hi, lo;
+        hi[0] = (_Float16)x0_; hi[1] = (_Float16)x1_; hi[2] = (_Float16)x2_; hi[3] = (_Float16)x3_;
+        lo[0] = (_Float16)(x0_ - (float)hi[0]); lo[1] = (_Float16)(x1_ - (float)hi[1]);
+        lo[2] = (_Float16)(x2_ - (float)hi[2]); lo[3] = (_Float16)(x3_ - (float)hi[3]);
+        _Float16* row = reinterpret_cast<_Float16*>(&s_in[(py * IN_PITCH + px) * KCP]);
+        *reinterpret_cast<f16x4*>(row + 4 * q) = hi;
+        *reinterpret_cast<f16x4*>(row + 16 + 4 * q) = lo;
+      }
     }
     const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
     for (int g = tid; g < TAPS * N * Q; g += 256) {
@@ -110,32 +138,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 1, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 1;
-      float av[2][KH], bv[NT][KH];
+      if (PREC == 0) {
+        float av[2][KH], bv[NT][KH];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float* p = &s_in[a_base + ((2 * m + dy) * IN_PITCH + dx) * KCP];
+        for (int m = 0; m < 2; ++m) {
+          const float* p = &s_in[a_base + ((2 * m + dy) * IN_PITCH + dx) * KCP];
 #pragma unroll
-        for (int j = 0; j < KH; j += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(p + j);
-          av[m][j] = t.x; av[m][j + 1] = t.y; av[m][j + 2] = t.z; av[m][j + 3] = t.w;
+          for (int j = 0; j < KH; j += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + j);
+            av[m][j] = t.x; av[m][j + 1] = t.y; av[m][j + 2] = t.z; av[m][j + 3] = t.w;
+          }
         }
-      }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float* p = &s_w[b_base + (tap * N + n * 32) * KCP];
+        for (int n = 0; n < NT; ++n) {
+          const float* p = &s_w[b_base + (tap * N + n * 32) * KCP];
 #pragma unroll
-        for (int j = 0; j < KH; j += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(p + j);
-          bv[n][j] = t.x; bv[n][j + 1] = t.y; bv[n][j + 2] = t.z; bv[n][j + 3] = t.w;
+          for (int j = 0; j < KH; j += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + j);
+            bv[n][j] = t.x; bv[n][j + 1] = t.y; bv[n][j + 2] = t.z; bv[n][j + 3] = t.w;
+          }
         }
-      }
 #pragma unroll
-      for (int j = 0; j < KH; ++j)
+        for (int j = 0; j < KH; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j], bv[n][j], acc[m][n], 0, 0, 0);
+      } else {
+        // lane (i,h): k = 8h..8h+7 of the 16-channel chunk; hi block at +0, lo block at +8 floats (32 B)
+        f16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float* p = &s_in[a_base16 + ((2 * m + dy) * IN_PITCH + dx) * KCP];
+          ah[m] = *reinterpret_cast<const f16x8*>(p);
+          al[m] = *reinterpret_cast<const f16x8*>(p + 8);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float* p = &s_w[b_base16 + (tap * N + n * 32) * KCP];
+          bh[n] = *reinterpret_cast<const f16x8*>(p);
+          bl[n] = *reinterpret_cast<const f16x8*>(p + 8);
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j], bv[n][j], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          }
+      }
     }
   }
 
@@ -235,15 +288,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   }
 }
 
-template <int KC, int NT, int TAPS>
+template <int KC, int NT, int TAPS, int PREC>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
+  static_assert(PREC == 0 || KC == 16, "split-fp16 mode walks K in chunks of 16 (one 32x32x16 MFMA)");
   constexpr int KCP = KC + 4;
   size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + TAPS * NT * 32 * KCP) * sizeof(float);
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
@@ -251,7 +305,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
   if (a.store == ST_NCHW && groups != 1) return -1002;  // planar outputs are <= 64 channels
-  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS>), dim3(grid, groups), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS, PREC>), dim3(grid, groups), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -259,12 +313,18 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   // npad is 32, or a multiple of 64 handled as npad/64 channel groups (blockIdx.y)
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32;
+  if (a.prec == 1) {
+    if (kc != 16) return -1003;
+    if (a.taps == 9) return one ? launch_t<16, 1, 9, 1>(a, s) : launch_t<16, 2, 9, 1>(a, s);
+    if (a.taps == 1) return one ? launch_t<16, 1, 1, 1>(a, s) : launch_t<16, 2, 1, 1>(a, s);
+    return -1000;
+  }
   if (a.taps == 9) {
-    if (kc == 16) return one ? launch_t<16, 1, 9>(a, s) : launch_t<16, 2, 9>(a, s);
-    if (kc == 8) return one ? launch_t<8, 1, 9>(a, s) : launch_t<8, 2, 9>(a, s);
+    if (kc == 16) return one ? launch_t<16, 1, 9, 0>(a, s) : launch_t<16, 2, 9, 0>(a, s);
+    if (kc == 8) return one ? launch_t<8, 1, 9, 0>(a, s) : launch_t<8, 2, 9, 0>(a, s);
   } else if (a.taps == 1) {
-    if (kc == 16) return one ? launch_t<16, 1, 1>(a, s) : launch_t<16, 2, 1>(a, s);
-    if (kc == 8) return one ? launch_t<8, 1, 1>(a, s) : launch_t<8, 2, 1>(a, s);
+    if (kc == 16) return one ? launch_t<16, 1, 1, 0>(a, s) : launch_t<16, 2, 1, 0>(a, s);
+    if (kc == 8) return one ? launch_t<8, 1, 1, 0>(a, s) : launch_t<8, 2, 1, 0>(a, s);
   }
   return -1000;
 }

@@ -61,7 +61,9 @@ struct ConvPack {
   int taps = 9;
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
+  size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows, scale * 2^-11
   size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
+  size_t w16_floats() const { return (size_t)((cin + 15) / 16) * taps * npad * 16; }
 };
 
 struct VecPack { size_t off = 0; int n = 0; };   // small per-channel vectors (LayerNorm g/b, depthwise w/b)
@@ -130,6 +132,7 @@ struct kp2d_model {
   float* blob = nullptr;
   bool finalized = false;
   int chunk_frames = 0;
+  int precision = KP2D_PREC_F16X3;
   bool profiling = false;
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -276,6 +279,8 @@ int describe(kp2d_model* m) {
     c.w_off = take(c.w_floats());
     c.sc_off = take(c.npad);
     c.sh_off = take(c.npad);
+    c.w16_off = take(c.w16_floats());
+    c.sc16_off = take(c.npad);
   }
   for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
   m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
@@ -354,6 +359,37 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
       }
     }
     (void)ngroups;
+    // split-fp16 pack (conv3x3.hip PREC 1): K walked in chunks of 16; each row is 16 hi halves then 16 lo
+    // halves of w * 2^11; the epilogue scale carries the 2^-11.
+    {
+      _Float16* h16 = reinterpret_cast<_Float16*>(&blob[c.w16_off]);
+      const int nchunk16 = (c.cin + 15) / 16;
+      for (int q = 0; q < c.npad; ++q) {
+        int co = -1;
+        if (q < c.cout) co = c.shuffle ? 4 * (q % cq) + (q / cq) : q;
+        blob[c.sc16_off + q] = co >= 0 ? sc[co] * (1.0f / 2048.0f) : 0.f;
+        if (co < 0) continue;
+        const int grp = q / ng, n = q % ng;
+        for (int ci = 0; ci < c.cin; ++ci) {
+          const int chk = ci / 16, kk = ci % 16;
+          for (int tap = 0; tap < c.taps; ++tap) {
+            float wv;
+            if (c.kind == 0) wv = w[((size_t)co * c.cin + ci) * 9 + tap];
+            else if (c.kind == 1) wv = w[(size_t)co * c.cin + ci];
+            else {
+              const int Cq = c.cin / 4, dy = ci / (2 * Cq), dx = (ci / Cq) & 1, cc = ci % Cq;
+              wv = w[(((size_t)co * Cq + cc) * 2 + dy) * 2 + dx];
+            }
+            wv *= 2048.0f;
+            const _Float16 hi = (_Float16)wv;
+            const _Float16 lo = (_Float16)(wv - (float)hi);
+            const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + tap) * ng + n) * 32;   // in halves
+            h16[row + kk] = hi;
+            h16[row + 16 + kk] = lo;
+          }
+        }
+      }
+    }
   }
   for (const auto& kv : m->vecs) {
     const auto& src = *host_get(m, kv.first);
@@ -431,16 +467,21 @@ struct Plan {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     ConvArgs a{};
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
-    a.w = m->blob + c.w_off; a.scale = m->blob + c.sc_off; a.shift = m->blob + c.sh_off;
+    const bool split = m->precision == KP2D_PREC_F16X3;
+    a.prec = split ? 1 : 0;
+    a.w = m->blob + (split ? c.w16_off : c.w_off);
+    a.scale = m->blob + (split ? c.sc16_off : c.sc_off);
+    a.shift = m->blob + c.sh_off;
     a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
     a.B = B; a.H = Hc; a.W = Wc; a.cin = c.cin; a.cout = c.cout; a.npad = c.npad;
     a.act = act; a.store = store; a.nsplit = nsplit;
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
-    const char* fam = c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32";
+    const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
+                            : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
-    check(launch_conv3x3(a, c.kc, stream), name.c_str());
+    check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
     prof_end();
   }
   // generic conv over dense NHWC activations: in1 may be null (no concat).  Channel slices via (c0, o0).
@@ -695,13 +736,18 @@ int validate_shape(const kp2d_model* m, int B, int H, int W) {
   return KP2D_OK;
 }
 
+size_t plan_bytes(kp2d_model* m, int Bc, int H, int W);
+
+// Frames per internal sub-batch.  Measured on MI355X (profiles/r1_*): the path is compute-bound, so bigger
+// launches win (64 frames at once: 5.4k frames/s vs 3.7k with 10-frame sub-batches that keep intermediates
+// inside the Infinity Cache but leave the 30x40 layers with 60 workgroups for 256 CUs).  The automatic
+// choice therefore only caps the workspace (4 GiB), it does not chase cache residency.
 int auto_chunk(const kp2d_model* m, int B, int H, int W) {
   if (m->chunk_frames > 0) return std::min(B, m->chunk_frames);
-  // keep one sub-batch's live activations (~60 B per input pixel per unit of c4/64) inside the Infinity Cache
-  const double per_frame = 60.0 * H * W * (m->c4 / 64.0) * 4.0;
-  int c = (int)(192.0 * 1024 * 1024 / per_frame);
-  c = std::max(4, std::min(c, 32));
-  return std::min(B, c);
+  const size_t per_frame = plan_bytes(const_cast<kp2d_model*>(m), 1, H, W);
+  if (per_frame == 0) return 1;
+  const size_t cap = (size_t)4 << 30;
+  return (int)std::max<size_t>(1, std::min<size_t>((size_t)B, cap / per_frame));
 }
 
 size_t plan_bytes(kp2d_model* m, int Bc, int H, int W) {
@@ -914,6 +960,14 @@ int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** 
   if (ms) HIP_TRY(hipEventElapsedTime(ms, r.e0, r.e1));
   return KP2D_OK;
 }
+
+int kp2d_set_precision(kp2d_model* m, int mode) {
+  if (!m || (mode != KP2D_PREC_FP32 && mode != KP2D_PREC_F16X3)) return fail(KP2D_ERR_ARG, "precision must be KP2D_PREC_FP32 or KP2D_PREC_F16X3");
+  m->precision = mode;
+  return KP2D_OK;
+}
+
+int kp2d_get_precision(const kp2d_model* m) { return m ? m->precision : KP2D_ERR_ARG; }
 
 int kp2d_set_chunk_frames(kp2d_model* m, int frames) {
   if (!m || frames < 0) return fail(KP2D_ERR_ARG, "bad argument");

@@ -34,6 +34,7 @@ struct ConvSrc { const float* p; int c, o; long bs, rs, ps; };   // channels tak
 struct ConvArgs {
   ConvSrc in0, in1;
   int taps;                           // 9 or 1
+  int prec;                           // 0: exact fp32 MFMA, 1: split-fp16 3xMFMA (weights packed as hi|lo halves)
   const float* w;                     // packed [group][cin_pad/KC][taps][ng][KC]
   const float* scale;                 // [npad]  BN: gamma/sqrt(var+eps); bias conv: 1
   const float* shift;                 // [npad]  BN: beta - mean*scale;   bias conv: bias

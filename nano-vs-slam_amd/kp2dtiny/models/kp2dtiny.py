@@ -20,6 +20,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import inspect
+import os
 
 import torch
 from torch import nn
@@ -322,7 +323,23 @@ class _KP2DTinyBase(nn.Module):
         if eng.signature != sig:
             eng.upload(self.state_dict())
             eng.signature = sig
+        self._apply_precision(eng)
         return eng
+
+    def _apply_precision(self, eng):
+        mode = _lib.PRECISIONS.get(self.__dict__.get("_precision") or os.environ.get("KP2D_PRECISION", "f16x3"))
+        if mode is None:
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        if eng.lib.kp2d_get_precision(eng.handle) != mode:
+            _lib.check(eng.lib.kp2d_set_precision(eng.handle, mode))
+
+    def set_precision(self, name: str):
+        """'f16x3' (default): split-fp16 matrix-core products with fp32 accumulation, fp32-grade error;
+        'fp32': exact fp32 matrix-core products.  Extension of this build (the reference has one arithmetic)."""
+        if name not in _lib.PRECISIONS:
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        self.__dict__["_precision"] = name
+        return self
 
     # ---- packed-weight exchange for multi-GPU frame sharding (sharding.py) ----------------------
     def packed_weights(self, device) -> torch.Tensor:
@@ -348,6 +365,7 @@ class _KP2DTinyBase(nn.Module):
         s = torch.cuda.current_stream(dev)
         _lib.check(eng.lib.kp2d_import_packed(eng.handle, _ptr(buf), C.c_void_p(s.cuda_stream)))
         eng.signature = self._weights_signature()
+        self._apply_precision(eng)
 
     # ---- reference API ------------------------------------------------------------------------
     def forward(self, x):

@@ -36,12 +36,15 @@ def _same_set(a, b, scores, boundary, tol=2e-5):
     assert np.all(np.abs(scores[diff] - boundary) <= tol), (diff, scores[diff])
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", golden_names())
-def test_against_reference_golden(name):
+def test_against_reference_golden(name, precision):
+    """Both arithmetic modes of the conv kernels (exact fp32 MFMA, split-fp16 3xMFMA) meet the same bar."""
     from nano_vs_slam_amd.selectors import select_keypoints, select_topk
     meta, z = load_golden(name)
     cfg, sd, x = golden_inputs(meta)
     model, _ = product_model(meta["config"], meta["v3"], meta["n_classes"])
+    model.set_precision(precision)
     H, W, st = meta["H"], meta["W"], meta["dense_stride"]
     fwd, post, post_np = _run(model, x, H, W)
     assert set(fwd) == {"score", "coord", "feat", "vlad", "seg"}
