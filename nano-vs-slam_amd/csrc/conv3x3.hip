@@ -99,19 +99,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   const float* src0 = a.in0.p + (size_t)b * a.in0.bs + a.in0.o;
   const float* src1 = a.in1.p + (size_t)b * a.in1.bs + a.in1.o;
   const int c0 = a.in0.c;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();
-    for (int g = tid; g < IN_ROWS * IN_ROWS * Q; g += 256) {
+  // Software pipeline over K chunks: the global loads of chunk c+1 are issued into registers before the
+  // MFMA loop of chunk c and only written to LDS (with the fp32 -> hi/lo split in PREC 1) after it, so the
+  // L2/HBM latency hides under the matrix-core work of this wave and of the co-resident workgroup.
+  constexpr int IN_G = IN_ROWS * IN_ROWS * Q;
+  constexpr int IN_IT = (IN_G + 255) / 256;
+  constexpr int W_G = TAPS * N * Q;
+  constexpr int W_IT = (W_G + 255) / 256;
+  float4 rin[IN_IT], rw[W_IT];
+
+  auto prefetch = [&](int ch) {
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const int g = tid + 256 * it;
       const int p = g / Q, q = g - p * Q;
       const int py = p / IN_ROWS, px = p - py * IN_ROWS;
       const int gy = y0 - 1 + py, gx = x0 - 1 + px;
       const int c = ch * KC + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin) {
+      if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin) {
         const float* src = (c < c0) ? src0 + gy * a.in0.rs + gx * a.in0.ps + c
                                     : src1 + gy * a.in1.rs + gx * a.in1.ps + (c - c0);
         v = *reinterpret_cast<const float4*>(src);
       }
+      rin[it] = v;
+    }
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int g = tid + 256 * it;
+      rw[it] = (W_G % 256 == 0 || g < W_G) ? wsrc[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const int g = tid + 256 * it;
+      if (IN_G % 256 != 0 && g >= IN_G) continue;
+      const int p = g / Q, q = g - p * Q;
+      const int py = p / IN_ROWS, px = p - py * IN_ROWS;
+      const float4 v = rin[it];
       if (PREC == 0) {
         *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
       } else {
@@ -128,12 +156,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
         *reinterpret_cast<f16x4*>(row + 16 + 4 * q) = lo;
       }
     }
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
-    for (int g = tid; g < TAPS * N * Q; g += 256) {
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int g = tid + 256 * it;
+      if (W_G % 256 != 0 && g >= W_G) continue;
       const int row = g / Q, q = g - row * Q;
-      *reinterpret_cast<float4*>(&s_w[row * KCP + 4 * q]) = wsrc[g];
+      *reinterpret_cast<float4*>(&s_w[row * KCP + 4 * q]) = rw[it];
     }
+  };
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();          // every wave is done reading the previous chunk's LDS image
+    commit();
     __syncthreads();
+    if (ch + 1 < nchunk) prefetch(ch + 1);
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
