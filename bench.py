@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md "~2.5 PF")
 PEAK_HBM_GBS = 8000.0
 LAYER_BOUNDARY_MB = {(240, 320): 123.86, (120, 160): 30.96, (480, 640): 495.44}
 
@@ -50,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--precision", default=os.environ.get("KP2D_PRECISION", "f16x3"), choices=["f16x3", "fp32"])
     return ap.parse_args()
 
 
@@ -168,6 +170,7 @@ def main():
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
     model = model.to(dev).eval()
     model.training = False
+    model.set_precision(args.precision)
     if world > 1:
         broadcast_model_weights(model, dev, src=0)   # the one RCCL collective of the job
 
@@ -210,8 +213,13 @@ def main():
         a = agg[dom]
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         total_ms = sum(v["ms"] for v in agg.values())
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        split = "f16x3" in dom
+        # f16x3: one fp32-grade product = three fp16 MFMAs, so the algorithmic peak is the fp16 peak / 3
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "peak_note": ("dense fp16 MFMA 2516.6 TFLOP/s / 3 MFMAs per fp32-grade product (xh*wh + xh*wl + xl*wh)"
+                              if split else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
                 "launches_per_step": a["launches"] // args.profile_steps,
                 "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                 "share_of_kernel_time": round(a["ms"] / total_ms, 4),
@@ -224,7 +232,9 @@ def main():
             "metric": "frames/sec KP2DTiny-S 240x320 multitask infer",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade)" if args.precision == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"KP2DTiny-{args.config}{'-V3' if args.v3 else ''} {H}x{W}, batch {B}/GPU, "
                                    f"all heads (score/loc/desc/seg/NetVLAD) + post_processing + top-{args.top_k} selection",
                        "global_batch": world * B, "frame_shards": world, "n_classes": args.n_classes},
