@@ -32,29 +32,12 @@
 //           relative, so the result is fp32-grade: measured max error vs fp64 1.7e-6 at K = 576 against
 //           1.9e-6 for the exact fp32 chain (tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log).
 //           3 MFMAs of 16x the fp32 rate -> 5.3x fewer matrix-core cycles per product.
-#include "kp2d_kernels.h"
+#include "conv_common.h"
 
 namespace kp2d {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int TILE = 16;
 constexpr int IN_ROWS = 18;
 constexpr int IN_PITCH = 24;
-
-__device__ __forceinline__ float act_apply(float v, int act, int ch) {
-  switch (act) {
-    case ACT_LEAKY: return v >= 0.f ? v : v * 0.01f;
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case ACT_TANH: return tanhf(v);
-    case ACT_SIGMOID0_TANH: return ch == 0 ? 1.f / (1.f + expf(-v)) : tanhf(v);
-    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-    default: return v;
-  }
-}
 
 template <int KC, int NT, int TAPS, int PREC>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
@@ -229,100 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
     }
   }
 
-  // ---------------- epilogue ----------------
-  // accumulator register r of lane (i,h) in M-tile m: channel = n*32+i,
-  // pixel row = wave*4 + 2m + ((r>>1)&1), col = 2*(h + 2*(r>>2)) + (r&1)
-  const int store = a.store;
-  if (store == ST_NCHW) {
-    // transpose through LDS so each channel plane is written in 16-pixel rows
-    constexpr int OP = 257;
-    __syncthreads();
-    float* s_out = smem;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = n * 32 + i;
-      const float sc = a.scale[n0 + co], sh = a.shift[n0 + co];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ry = wave * 4 + 2 * m + ((r >> 1) & 1);
-          const int cx = 2 * (h + 2 * (r >> 2)) + (r & 1);
-          s_out[co * OP + ry * TILE + cx] = acc[m][n][r] * sc + sh;
-        }
-    }
-    __syncthreads();
-    const int ry = tid >> 4, cx = tid & 15;
-    const int y = y0 + ry, x = x0 + cx;
-    if (y < H && x < W) {
-      const size_t plane = (size_t)H * W;
-      const size_t pofs = (size_t)y * W + x;
-      if (a.act == ACT_SOFTMAX_C) {
-        float mx = -INFINITY;
-        for (int co = 0; co < a.cout; ++co) mx = fmaxf(mx, s_out[co * OP + tid]);
-        float sum = 0.f;
-        for (int co = 0; co < a.cout; ++co) sum += expf(s_out[co * OP + tid] - mx);
-        const float inv = 1.f / sum;
-        for (int co = 0; co < a.cout; ++co)
-          a.out0[((size_t)b * a.cout + co) * plane + pofs] = expf(s_out[co * OP + tid] - mx) * inv;
-      } else {
-        const int ns = a.nsplit;
-        for (int co = 0; co < a.cout; ++co) {
-          const float v = act_apply(s_out[co * OP + tid], a.act, co);
-          if (co < ns) a.out0[((size_t)b * ns + co) * plane + pofs] = v;
-          else a.out1[((size_t)b * (a.cout - ns) + (co - ns)) * plane + pofs] = v;
-        }
-      }
-    }
-    return;
-  }
-
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int co = n0 + n * 32 + i;
-    const float sc = a.scale[co], sh = a.shift[co];
-    const bool cok = co < a.cout;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = act_apply(acc[m][n][r] * sc + sh, a.act, co);
-      const int ybase = y0 + wave * 4 + 2 * m;
-      if (store == ST_NHWC || store == ST_NHWC_BOTH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int y = ybase + ((r >> 1) & 1);
-          const int x = x0 + 2 * (h + 2 * (r >> 2)) + (r & 1);
-          if (cok && y < H && x < W) a.out0[(((size_t)b * H + y) * W + x) * a.os0 + a.oo0 + co] = v[r];
-        }
-      }
-      if (store == ST_NHWC_POOL || store == ST_NHWC_BOTH) {
-        const int Hp = H >> 1, Wp = W >> 1;
-        const int yp = ybase >> 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float p = fmaxf(fmaxf(v[4 * g], v[4 * g + 1]), fmaxf(v[4 * g + 2], v[4 * g + 3]));
-          const int xp = (x0 >> 1) + h + 2 * g;
-          if (cok && yp < Hp && xp < Wp) a.out1[(((size_t)b * Hp + yp) * Wp + xp) * a.os1 + a.oo1 + co] = p;
-        }
-      }
-      if (store == ST_SHUFFLE) {
-        // packed channel position co -> (sub-pixel, channel): sub = co / (cout/4), c = co % (cout/4);
-        // the packer permuted the rows so that original channel 4c + sub sits at position co.
-        const int cq = a.cout >> 2;
-        const int sub = co / cq, c = co - sub * cq;
-        const int ii = sub >> 1, jj = sub & 1;
-        const int H2 = 2 * H, W2 = 2 * W;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int y = ybase + ((r >> 1) & 1);
-          const int x = x0 + 2 * (h + 2 * (r >> 2)) + (r & 1);
-          if (cok && y < H && x < W)
-            a.out0[(((size_t)b * H2 + 2 * y + ii) * W2 + 2 * x + jj) * a.os0 + a.oo0 + c] = v[r];
-        }
-      }
-    }
-  }
+#include "conv_epilogue.inc"
 }
 
 template <int KC, int NT, int TAPS, int PREC>
@@ -417,6 +307,20 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
       }
     }
     float4* dst = reinterpret_cast<float4*>(a.out + p * CO);
+    if (a.out_s16) {
+      // CO == 16: one S16 block = [16 hi halves][16 lo halves]
+      f16x8 hv[2], lv[2];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float v = act_apply(acc[c] * s_sc[c] + s_sh[c], a.act, c);
+        const _Float16 hi = (_Float16)v;
+        hv[c >> 3][c & 7] = hi;
+        lv[c >> 3][c & 7] = (_Float16)(v - (float)hi);
+      }
+      f16x8* d16 = reinterpret_cast<f16x8*>(dst);
+      d16[0] = hv[0]; d16[1] = hv[1]; d16[2] = lv[0]; d16[3] = lv[1];
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < CO; c += 4) {
       float4 o;

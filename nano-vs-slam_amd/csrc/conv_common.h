@@ -1,0 +1,42 @@
+// Shared pieces of the convolution kernels: activation selector and the accumulator epilogue
+// (per-channel affine, activation, and the store modes of kp2d_kernels.h::Store).
+#pragma once
+#include "kp2d_kernels.h"
+
+namespace kp2d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = 16;
+
+// kept out of line: it is inlined 64x per thread otherwise and bloats the kernels past the instruction cache
+__device__ __attribute__((noinline)) float act_apply(float v, int act, int ch) {
+  switch (act) {
+    case ACT_LEAKY: return v >= 0.f ? v : v * 0.01f;
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID0_TANH: return ch == 0 ? 1.f / (1.f + expf(-v)) : tanhf(v);
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    default: return v;
+  }
+}
+
+// "S16" activation format (f16x3 mode): a pixel's channels in blocks of 16, each block 64 B =
+// [16 x fp16 hi][16 x fp16 lo] with hi = fp16(x), lo = fp16(x - hi) — the operand form the split-fp16 MFMA
+// consumes, written once by the producer instead of being re-derived by every consumer workgroup.
+// Lane pairs (even, odd channel) exchange halves so each lane still issues one 4-byte store per value:
+// the even lane stores the two hi halves, the odd lane the two lo halves.  Returns the dword to store and
+// the float-slot offset inside the pixel for channel `ch` (ch = this lane's channel).
+__device__ __forceinline__ unsigned s16_pair(float v, int lane_odd) {
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+  const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+  return lane_odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+}
+__device__ __forceinline__ int s16_slot(int ch) { return ((ch >> 4) << 4) + ((ch & 1) << 3) + ((ch & 15) >> 1); }
+
+}  // namespace kp2d

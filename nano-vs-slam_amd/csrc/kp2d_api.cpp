@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,6 +63,8 @@ struct ConvPack {
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
   size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows, scale * 2^-11
+  size_t w16s_off = 0;                        // same rows, staged order [chunk][dy][dx][n] + quad swizzle (conv_s16.hip)
+  bool s16_capable() const { return kind == 0 && (cin % 16) == 0; }
   size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
   size_t w16_floats() const { return (size_t)((cin + 15) / 16) * taps * npad * 16; }
 };
@@ -113,6 +116,7 @@ struct Arena {
 struct Act {
   size_t off = 0, bytes = 0;
   int C = 0, H = 0, W = 0;
+  bool s16 = false;   // pre-split [16 hi | 16 lo] fp16 blocks (conv_common.h) instead of fp32; same byte size
 };
 
 }  // namespace
@@ -133,6 +137,10 @@ struct kp2d_model {
   bool finalized = false;
   int chunk_frames = 0;
   int precision = KP2D_PREC_F16X3;
+  bool s16_ok = false;    // every activation width is a multiple of 16 -> pre-split activations + LDS-DMA conv
+  bool no_dma = true;     // KP2D_DMA=1 switches f16x3 to pre-split (S16) activations + the LDS-DMA conv kernel
+                          // (conv_s16.hip).  Measured round 1: 12.7k frames/s vs 14.0k for the register-staged
+                          // kernel, so it is opt-in until its pipeline is deeper.
   bool profiling = false;
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -281,6 +289,7 @@ int describe(kp2d_model* m) {
     c.sh_off = take(c.npad);
     c.w16_off = take(c.w16_floats());
     c.sc16_off = take(c.npad);
+    if (c.s16_capable()) c.w16s_off = take(c.w16_floats());
   }
   for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
   m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
@@ -386,6 +395,15 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
             const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + tap) * ng + n) * 32;   // in halves
             h16[row + kk] = hi;
             h16[row + 16 + kk] = lo;
+            if (c.s16_capable()) {
+              // conv_s16.hip: slab per (chunk, dy) = rows r = dx*ng + n; 16-byte quad j of a row
+              // (0: hi k0-7, 1: hi k8-15, 2: lo k0-7, 3: lo k8-15) is stored at position j ^ ((r >> 2) & 3)
+              _Float16* s16 = reinterpret_cast<_Float16*>(&blob[c.w16s_off]);
+              const int dy = tap / 3, dx = tap % 3, r = dx * ng + n, swz = (r >> 2) & 3;
+              const size_t rowb = ((((size_t)grp * nchunk16 + chk) * 3 + dy) * 3 * ng + r) * 32;
+              s16[rowb + (((kk >> 3) ^ swz) << 3) + (kk & 7)] = hi;
+              s16[rowb + (((2 + (kk >> 3)) ^ swz) << 3) + (kk & 7)] = lo;
+            }
           }
         }
       }
@@ -418,6 +436,7 @@ struct Plan {
   char* ws;
   Arena arena;
   bool dry = false;       // only size the arena
+  bool s16_mode = false;  // f16x3 + every channel count a multiple of 16: activations travel pre-split (S16)
   int B, H, W;
   int rc = KP2D_OK;
 
@@ -461,15 +480,20 @@ struct Plan {
     return s;
   }
   // core launch: sources already described
+  bool in_s16 = false;        // format of the sources / destinations of the NEXT conv_src call (set by callers)
+  int out_s16[2] = {0, 0};
   void conv_src(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
                 int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
     if (rc != KP2D_OK || dry) return;
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     ConvArgs a{};
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
+    a.out0_s16 = out_s16[0]; a.out1_s16 = out_s16[1];
     const bool split = m->precision == KP2D_PREC_F16X3;
+    const bool dma = in_s16;   // S16 inputs -> LDS-DMA kernel
+    if (dma && !(split && c.s16_capable())) { rc = fail(KP2D_ERR_STATE, "%s: S16 input reached a layer without an S16 kernel", name.c_str()); return; }
     a.prec = split ? 1 : 0;
-    a.w = m->blob + (split ? c.w16_off : c.w_off);
+    a.w = m->blob + (dma ? c.w16s_off : (split ? c.w16_off : c.w_off));
     a.scale = m->blob + (split ? c.sc16_off : c.sc_off);
     a.shift = m->blob + c.sh_off;
     a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
@@ -478,11 +502,12 @@ struct Plan {
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
-    const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
+    const char* fam = dma ? "conv3x3_s16dma" : split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
                             : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
-    check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
+    check(dma ? launch_conv3x3_s16(a, stream) : launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
     prof_end();
+    out_s16[0] = out_s16[1] = 0;
   }
   // generic conv over dense NHWC activations: in1 may be null (no concat).  Channel slices via (c0, o0).
   void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
@@ -490,12 +515,17 @@ struct Plan {
     if (rc != KP2D_OK || dry) return;
     ConvSrc s0 = dense(ptr(in0), in0, c0, o0);
     ConvSrc s1 = in1 ? dense(ptr(*in1), *in1, in1->C, 0) : dense(ptr(in0), in0, 0, 0);
+    if (in1 && in1->s16 != in0.s16) { rc = fail(KP2D_ERR_STATE, "%s: concat of mixed activation formats", name.c_str()); return; }
+    in_s16 = in0.s16;
     conv_src(name, s0, s1, act, store, out0, os0, oo0, out1, os1, oo1, nsplit, Hc, Wc);
+    in_s16 = false;
   }
   // 1x1 conv -> NHWC activation
-  Act pw(const std::string& name, const Act& in, int act, int store = ST_NHWC) {
+  Act pw(const std::string& name, const Act& in, int act, int store = ST_NHWC, bool s16out = false) {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     Act out{};
+    const bool fmt = s16_mode && s16out;
+    out_s16[0] = out_s16[1] = fmt ? 1 : 0;
     if (store == ST_NHWC_POOL) {
       out = alloc(c.cout, in.H / 2, in.W / 2);
       conv(name, in, in.C, 0, nullptr, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, in.H, in.W);
@@ -503,6 +533,8 @@ struct Plan {
       out = alloc(c.cout, in.H, in.W);
       conv(name, in, in.C, 0, nullptr, act, ST_NHWC, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, in.H, in.W);
     }
+    out.s16 = fmt;
+    out_s16[0] = out_s16[1] = 0;
     return out;
   }
   Act layernorm(const std::string& prefix, const Act& in) {
@@ -517,7 +549,7 @@ struct Plan {
     return out;
   }
   // SegFormerAttentionModule.forward (modules/segformer.py:217-220); `pool` folds the following MaxPool2d(2,2)
-  Act attention_module(const std::string& p, const Act& x, bool pool) {
+  Act attention_module(const std::string& p, const Act& x, bool pool, bool s16out) {
     const int C = x.C, h = x.H, w = x.W;
     Act ln1 = layernorm(p + ".att.norm", x);
     Act q = pw(p + ".att.fn.to_q", ln1, ACT_NONE);
@@ -560,16 +592,18 @@ struct Plan {
     release(f0);
     Act f2 = pw(p + ".mff.fn.net.1.net.1", f1, ACT_GELU);
     release(f1);
-    Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC);
+    Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC, s16out);
     release(f2);
     return f3;
   }
   // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
-  Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr) {
+  Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr, bool s16out = true) {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     const int act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
     const int Hc = in0.H, Wc = in0.W;
     Act out{};
+    const bool fmt = s16_mode && s16out;
+    out_s16[0] = out_s16[1] = fmt ? 1 : 0;
     if (store == ST_NHWC) {
       out = alloc(c.cout, Hc, Wc);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, Hc, Wc);
@@ -585,6 +619,9 @@ struct Plan {
       out = alloc(c.cout / 4, Hc * 2, Wc * 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
+    out.s16 = fmt;
+    if (pooled) pooled->s16 = fmt;
+    out_s16[0] = out_s16[1] = 0;
     return out;
   }
 };
@@ -608,11 +645,13 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Conv1aArgs a{};
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
     a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk;
+    a.out_s16 = P.s16_mode ? 1 : 0;
     const double px = (double)B * H * W;
     P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 27 * m->c1 * px, 4.0 * px * (3 + m->c1));
     P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
     P.prof_end();
   }
+  t1a.s16 = P.s16_mode;
   Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC);
   P.release(t1a);
   Act t2a = P.cbr("backbone.conv2a", p1, nullptr, ST_NHWC);
@@ -646,7 +685,10 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act d1 = P.cbr("desc_head.convA", xb, nullptr, ST_NHWC);
     const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
     Act d2 = P.alloc(cB.cout / 4, H2, W2);
+    d2.s16 = P.s16_mode;
+    P.out_s16[0] = d2.s16 ? 1 : 0;
     P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+    P.out_s16[0] = 0;
     P.release(d1);
     Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
     P.release(d2);
@@ -659,10 +701,10 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act g5{};
     int i;   // index of the CBR(c_exp -> c_hidden) layer
     if (g.use_attention) {
-      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
-      Act a1 = P.attention_module("seg_head.convs.1", g0, /*pool=*/true);
+      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // feeds LayerNorm
+      Act a1 = P.attention_module("seg_head.convs.1", g0, /*pool=*/true, /*s16out=*/false);
       P.release(g0);
-      Act a2 = P.attention_module("seg_head.convs.2", a1, false);
+      Act a2 = P.attention_module("seg_head.convs.2", a1, false, /*s16out=*/true);          // feeds convs.3
       P.release(a1);
       Act g4 = P.cbr("seg_head.convs.3", a2, nullptr, ST_SHUFFLE);
       P.release(a2);
@@ -706,7 +748,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act v1 = P.cbr("vlad_head.convlad1", xb, nullptr, ST_NHWC);
     Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
     P.release(v1);
-    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
+    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // NetVLAD reads fp32
     P.release(v2);
     const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
     const int ns = netvlad_nsplit(S);
@@ -784,6 +826,11 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   if (cfg->n_classes < 1 || cfg->n_classes > 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "n_classes must be in [1,32]"); }
   int rc = describe(m);
   if (rc != KP2D_OK) { delete m; return rc; }
+  m->s16_ok = true;
+  for (int v : {m->c1, m->c2, m->c3, m->c4, m->c5, m->d1 / 4, cfg->encoder_dim}) m->s16_ok = m->s16_ok && (v % 16 == 0);
+  if (cfg->version == 3) m->s16_ok = m->s16_ok && ((m->c5 / 2) % 16 == 0);
+  const char* nd = getenv("KP2D_DMA");
+  m->no_dma = !(nd && nd[0] == '1');
   *out = m;
   return KP2D_OK;
 }
@@ -877,6 +924,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     Plan P{};
     P.m = m; P.stream = (hipStream_t)stream; P.ws = (char*)workspace; P.dry = false;
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W;
+    P.s16_mode = m->precision == KP2D_PREC_F16X3 && m->s16_ok && !m->no_dma;
     P.arena.reset(workspace_bytes);
     FwdOut o{};
     o.x = x + (size_t)b0 * 3 * H * W;
