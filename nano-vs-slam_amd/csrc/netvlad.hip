@@ -118,6 +118,132 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
   if (tid < K) dst[KC_ + tid] = asum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core version of pass 1 (K in {32, 64}, C <= 64): per 64-pixel tile
+//   step 1  logits^T[k][p] = sum_c Wa[k][c] xh[p][c]      one 32x32 (k-tile, p-tile) block per wave
+//   softmax over k per pixel (4 threads per pixel, through LDS)
+//   step 2  V[k][c] += sum_p a[p][k] xh[p][c]             one 32x32 (k-tile, c-tile) block per wave, the
+//                                                         accumulator stays in registers over the whole slab
+// Exact fp32 (v_mfma_f32_32x32x2_f32).  In both products lane (i, h) walks the contraction index as
+// 32h + s, s = 0..31, so step 1 reads its operands as 8 ds_read_b128 per row (row pitch 68 floats).
+// ---------------------------------------------------------------------------------------------
+typedef float vf16 __attribute__((ext_vector_type(16)));
+constexpr int VP = 68;   // LDS row pitch (floats) of the [row][channel] images
+constexpr int AP = 65;   // LDS row pitch of the [pixel][cluster] assignment image
+
+template <int KT>
+__global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int KPAD = 32 * KT;
+  float* s_w = sm;                   // [KPAD][VP]   soft-assign weights, channels zero-padded to 64
+  float* s_x = s_w + KPAD * VP;      // [64][VP]     normalised descriptors of the tile
+  float* s_a = s_x + VT * VP;        // [64][AP]     logits, then soft assignments
+  const int C = a.C, K = a.K, S = a.S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int per = (S + a.nsplit - 1) / a.nsplit;
+  const int s_begin = split * per;
+  const int s_end = min(S, s_begin + per);
+  const int CQ = C >> 2;
+
+  for (int e = tid; e < KPAD * 16; e += 256) {
+    const int k = e >> 4, q = e & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K && q < CQ) v = reinterpret_cast<const float4*>(a.wa + (size_t)k * C)[q];
+    *reinterpret_cast<float4*>(&s_w[k * VP + 4 * q]) = v;
+  }
+  for (int e = tid; e < VT * 16; e += 256)   // zero once: padded channels stay zero for every tile
+    *reinterpret_cast<float4*>(&s_x[(e >> 4) * VP + 4 * (e & 15)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // wave -> blocks: step 1 (k-tile kt1, p-tile pt1), step 2 (k-tile kt2, c-tile ct2)
+  const int kt1 = wave % KT, pt1 = wave / KT;          // KT == 2: 4 blocks; KT == 1: waves 0,1 only
+  const bool has1 = pt1 < 2;
+  const int kt2 = wave % KT, ct2 = wave / KT;
+  const bool has2 = ct2 < 2 && ct2 * 32 < C;
+  vf16 vacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) vacc[r] = 0.f;
+  float asum = 0.f;
+  const int p4 = tid >> 2, q4 = tid & 3;               // 4 threads per pixel
+  const int cq = C >> 2, kq = K >> 2;
+  const float* xb = a.x + (size_t)b * S * C;
+
+  for (int t0 = s_begin; t0 < s_end; t0 += VT) {
+    const int np = min(VT, s_end - t0);
+    __syncthreads();
+    for (int e = tid; e < VT * CQ; e += 256) {
+      const int pp = e / CQ, q = e - pp * CQ;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < np) v = reinterpret_cast<const float4*>(xb + (size_t)(t0 + pp) * C)[q];
+      *reinterpret_cast<float4*>(&s_x[pp * VP + 4 * q]) = v;
+    }
+    __syncthreads();
+    {  // descriptor-wise L2 normalisation (F.normalize, eps 1e-12)
+      float ss = 0.f;
+      for (int c = q4 * cq; c < (q4 + 1) * cq; ++c) { const float v = s_x[p4 * VP + c]; ss = fmaf(v, v, ss); }
+      ss += __shfl_xor(ss, 1);
+      ss += __shfl_xor(ss, 2);
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+      for (int c = q4 * cq; c < (q4 + 1) * cq; ++c) s_x[p4 * VP + c] *= inv;
+    }
+    __syncthreads();
+    if (has1) {   // step 1: logits^T block (rows k, cols p)
+      vf16 d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = 0.f;
+      const float* wr = &s_w[(kt1 * 32 + i) * VP + 32 * h];
+      const float* xr = &s_x[(pt1 * 32 + i) * VP + 32 * h];
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * s4);
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * s4);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, d, 0, 0, 0);
+      }
+      // D[row = k][col = p]: lane holds p = i, rows (r&3) + 8(r>>2) + 4h
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_a[(pt1 * 32 + i) * AP + kt1 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = d[r];
+    }
+    __syncthreads();
+    {  // softmax over clusters: this thread owns clusters [q4*kq, (q4+1)*kq) of pixel p4
+      float* row = &s_a[p4 * AP + q4 * kq];
+      float mx = -INFINITY;
+      for (int j = 0; j < kq; ++j) mx = fmaxf(mx, row[j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = fmaxf(mx, __shfl_xor(mx, 2));
+      float se = 0.f;
+      for (int j = 0; j < kq; ++j) { const float e = expf(row[j] - mx); row[j] = e; se += e; }
+      se += __shfl_xor(se, 1);
+      se += __shfl_xor(se, 2);
+      const float rs = (p4 < np) ? 1.f / se : 0.f;     // pixels past the slab contribute nothing
+      for (int j = 0; j < kq; ++j) row[j] *= rs;
+    }
+    __syncthreads();
+    if (has2) {   // step 2: V block (rows k, cols c), contraction over the tile's 64 pixels
+      const float* ar = &s_a[(32 * h) * AP + kt2 * 32 + i];
+      const float* xr = &s_x[(32 * h) * VP + ct2 * 32 + i];
+#pragma unroll 8
+      for (int s = 0; s < 32; ++s) vacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s * AP], xr[s * VP], vacc, 0, 0, 0);
+    }
+    if (tid < K)
+      for (int pp = 0; pp < VT; ++pp) asum += s_a[pp * AP + tid];
+  }
+  const int KC_ = K * C;
+  float* dst = a.part + ((size_t)b * a.nsplit + split) * (KC_ + K);
+  if (has2) {
+    const int c = ct2 * 32 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (c < C && k < K) dst[k * C + c] = vacc[r];
+    }
+  }
+  if (tid < K) dst[KC_ + tid] = asum;
+}
+
 __global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C, K = a.K, KC_ = K * C;
@@ -163,8 +289,15 @@ __global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
 
 int launch_netvlad(const VladArgs& a, hipStream_t s) {
   if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 4096 || a.K < 4) return -1100;
-  const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
-  hipLaunchKernelGGL(netvlad_partial_kernel, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+  if ((a.K == 32 || a.K == 64) && a.C <= 64) {
+    const int kt = a.K / 32;
+    const size_t lds = (size_t)(32 * kt * VP + VT * VP + VT * AP) * sizeof(float);
+    if (kt == 2) hipLaunchKernelGGL(netvlad_partial_mfma_kernel<2>, dim3(a.nsplit, a.B), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(netvlad_partial_mfma_kernel<1>, dim3(a.nsplit, a.B), dim3(256), lds, s, a);
+  } else {
+    const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
+    hipLaunchKernelGGL(netvlad_partial_kernel, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+  }
   const size_t lds2 = (size_t)(a.K * a.C + 2 * a.K + 8) * sizeof(float);
   hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(256), lds2, s, a);
   return (int)hipGetLastError();
