@@ -225,6 +225,16 @@ def main():
                 "share_of_kernel_time": round(a["ms"] / total_ms, 4),
                 "algorithmic_gb_per_s": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1),
                 "kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 3) for k, v in agg.items()}}
+        # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_collect.sh): bench.py
+        # cannot run rocprofv3 around itself, so the per-launch figure measured on this workload is read back
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if B == 64 and (H, W) == (240, 320) and dom in tr["kernels"]:
+                roof["traffic"] = round(tr["kernels"][dom]["bytes_per_launch"])
+                roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)"
+                roof["algorithmic_bytes_per_launch"] = round(a["bytes"] / a["launches"])
+        except (OSError, KeyError, ValueError):
+            pass
         lb = LAYER_BOUNDARY_MB.get((H, W))
         if lb and args.config == "S" and not args.v3:
             roof["hbm_layer_boundary_frac"] = round(fps / world * lb * 1e6 / (PEAK_HBM_GBS * 1e9), 4)

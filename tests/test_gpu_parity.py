@@ -237,3 +237,33 @@ def test_argument_errors():
     with pytest.raises(_lib.Kp2dError):
         from nano_vs_slam_amd.selectors import select_topk
         select_topk(torch.zeros(1, 10000, device=DEV), 5000)
+
+
+def test_entry_points_run(tmp_path):
+    """demo.py / eval_multitask.py equivalents keep the reference's model-facing call sequence."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "demo.py", "--frames", "3"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "keypoints/frame" in r.stdout, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "eval_multitask.py", "--keypoints", "--visloc", "--segmentation", "--n_batches", "2",
+                        "--config", "S", "--result_dir", str(tmp_path)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "self_recall@1" in r.stdout, r.stderr[-2000:]
+
+
+def test_inference_front_end_matches_oracle():
+    from nano_vs_slam_amd.pipeline import inference
+    model, sd = product_model("S", False, 28)
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    pts, feat, out = inference(model, frame, (64, 96), nn_thresh=0.5, top_k=50)
+    x = (frame.astype(np.float32) / 255.0 - 0.5) * 2.0
+    x = np.ascontiguousarray(x.transpose(2, 0, 1))[None]
+    cfg = orc.get_config("S")
+    ref = orc.post_processing(orc.forward(x, sd, cfg), 64, 96, cfg)
+    idx, rpts, rdesc = orc.select_k1(ref["score"], ref["coord"], ref["feat"], 0.5, 50)
+    assert pts.shape == rpts.shape and feat.shape == rdesc.shape
+    order = np.lexsort((pts[:, 0], pts[:, 1]))
+    rorder = np.lexsort((rpts[:, 0], rpts[:, 1]))
+    assert np.max(np.abs(pts[order] - rpts[rorder])) < 1e-3
+    assert np.max(np.abs(feat[order] - rdesc[rorder])) < 1e-3
