@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
       const int gy = y0 - 1 + py, gx = x0 - 1 + px;
       const int c = ch * KC + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin) {
+      if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin && !(a.dbg & 4)) {
         const float* src = (c < c0) ? src0 + gy * a.in0.rs + gx * a.in0.ps + c
                                     : src1 + gy * a.in1.rs + gx * a.in1.ps + (c - c0);
         v = *reinterpret_cast<const float4*>(src);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
       const int g = tid + 256 * it;
-      rw[it] = (W_G % 256 == 0 || g < W_G) ? wsrc[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[it] = ((W_G % 256 == 0 || g < W_G) && !(a.dbg & 4)) ? wsrc[g] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
 
@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
       const int p = g / Q, q = g - p * Q;
       const int py = p / IN_ROWS, px = p - py * IN_ROWS;
       const float4 v = rin[it];
-      if (PREC == 0) {
+      if (PREC == 0 || a.in_s16) {
+        // fp32 operands, or a producer that already wrote [16 hi | 16 lo] fp16 blocks (conv_common.h):
+        // the 64-byte block IS the LDS row
         *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
       } else {
         // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; |x| is clamped to the fp16 range
@@ -151,10 +153,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   prefetch(0);
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();          // every wave is done reading the previous chunk's LDS image
-    commit();
+    if (!(a.dbg & 2)) commit();
     __syncthreads();
     if (ch + 1 < nchunk) prefetch(ch + 1);
 
+    if (!(a.dbg & 8))
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 1, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 1;

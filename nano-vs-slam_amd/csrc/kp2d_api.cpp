@@ -138,9 +138,17 @@ struct kp2d_model {
   int chunk_frames = 0;
   int precision = KP2D_PREC_F16X3;
   bool s16_ok = false;    // every activation width is a multiple of 16 -> pre-split activations + LDS-DMA conv
-  bool no_dma = true;     // KP2D_DMA=1 switches f16x3 to pre-split (S16) activations + the LDS-DMA conv kernel
-                          // (conv_s16.hip).  Measured round 1: 12.7k frames/s vs 14.0k for the register-staged
-                          // kernel, so it is opt-in until its pipeline is deeper.
+  std::map<uint64_t, size_t> plan_cache;
+  int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
+  std::vector<hipStream_t> lane_streams;
+  std::vector<hipEvent_t> lane_events;
+  hipEvent_t fork_event = nullptr;
+  bool use_dma = false;   // KP2D_DMA=1: run S16 layers on the LDS-DMA kernel (conv_s16.hip) instead of the
+                          // register-staged one.  Measured round 1: 12.7k vs 14.0k frames/s, so it is opt-in
+                          // until its pipeline is deeper.
+  bool no_s16 = true;     // KP2D_S16=1: pre-split (S16) activations between conv layers in f16x3 mode.  Measured
+                          // round 1: the producer-side split costs more in the exposed epilogue than it saves in
+                          // the (hidden) staging conversion: 14.7k vs 15.5k frames/s, so fp32 activations stay default.
   bool profiling = false;
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -490,8 +498,10 @@ struct Plan {
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
     a.out0_s16 = out_s16[0]; a.out1_s16 = out_s16[1];
     const bool split = m->precision == KP2D_PREC_F16X3;
-    const bool dma = in_s16;   // S16 inputs -> LDS-DMA kernel
-    if (dma && !(split && c.s16_capable())) { rc = fail(KP2D_ERR_STATE, "%s: S16 input reached a layer without an S16 kernel", name.c_str()); return; }
+    if (in_s16 && !(split && c.s16_capable())) { rc = fail(KP2D_ERR_STATE, "%s: S16 input reached a layer without an S16 kernel", name.c_str()); return; }
+    const bool dma = in_s16 && m->use_dma;   // LDS-DMA kernel (opt-in); otherwise the register-staged kernel copies the S16 rows
+    a.in_s16 = in_s16 ? 1 : 0;
+    { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
     a.w = m->blob + (dma ? c.w16s_off : (split ? c.w16_off : c.w_off));
     a.scale = m->blob + (split ? c.sc16_off : c.sc_off);
@@ -792,7 +802,19 @@ int auto_chunk(const kp2d_model* m, int B, int H, int W) {
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)B, cap / per_frame));
 }
 
+size_t plan_bytes_uncached(kp2d_model* m, int Bc, int H, int W);
+
+// dry-run planning costs ~0.1 ms of host time; the result only depends on (frames, H, W), so it is memoised
 size_t plan_bytes(kp2d_model* m, int Bc, int H, int W) {
+  const uint64_t key = ((uint64_t)Bc << 40) ^ ((uint64_t)H << 20) ^ (uint64_t)W;
+  auto it = m->plan_cache.find(key);
+  if (it != m->plan_cache.end()) return it->second;
+  const size_t v = plan_bytes_uncached(m, Bc, H, W);
+  m->plan_cache[key] = v;
+  return v;
+}
+
+size_t plan_bytes_uncached(kp2d_model* m, int Bc, int H, int W) {
   Plan P{};
   P.m = m; P.stream = nullptr; P.ws = nullptr; P.dry = true; P.B = Bc; P.H = H; P.W = W;
   P.arena.reset((size_t)1 << 46);
@@ -830,7 +852,11 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   for (int v : {m->c1, m->c2, m->c3, m->c4, m->c5, m->d1 / 4, cfg->encoder_dim}) m->s16_ok = m->s16_ok && (v % 16 == 0);
   if (cfg->version == 3) m->s16_ok = m->s16_ok && ((m->c5 / 2) % 16 == 0);
   const char* nd = getenv("KP2D_DMA");
-  m->no_dma = !(nd && nd[0] == '1');
+  m->use_dma = nd && nd[0] == '1';
+  const char* nlanes = getenv("KP2D_LANES");
+  if (nlanes) m->lanes = std::max(1, std::min(8, atoi(nlanes)));
+  const char* ns = getenv("KP2D_S16");
+  m->no_s16 = !(ns && ns[0] == '1') && !m->use_dma;
   *out = m;
   return KP2D_OK;
 }
@@ -839,6 +865,9 @@ void kp2d_destroy(kp2d_model* m) {
   if (!m) return;
   if (m->blob) (void)hipFree(m->blob);
   for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto st : m->lane_streams) (void)hipStreamDestroy(st);
+  for (auto ev : m->lane_events) (void)hipEventDestroy(ev);
+  if (m->fork_event) (void)hipEventDestroy(m->fork_event);
   delete m;
 }
 
@@ -899,10 +928,31 @@ int kp2d_import_packed(kp2d_model* m, const void* dev_src, void* stream) {
   return KP2D_OK;
 }
 
+// Sub-batch schedule shared by kp2d_workspace_bytes and kp2d_forward: `lanes` concurrent streams, each working
+// through ceil(nchunks / lanes) sub-batches of `chunk` frames in its own slice of the workspace.
+static void schedule(const kp2d_model* m, int B, int H, int W, int* lanes, int* chunk) {
+  int nl = m->profiling ? 1 : std::max(1, m->lanes);
+  nl = std::min(nl, B);
+  int c = std::min(auto_chunk(m, B, H, W), (B + nl - 1) / nl);
+  *lanes = nl;
+  *chunk = std::max(1, c);
+}
+
 size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
   if (!m || validate_shape(m, B, H, W) != KP2D_OK) return 0;
-  const int chunk = auto_chunk(m, B, H, W);
-  return plan_bytes(const_cast<kp2d_model*>(m), chunk, H, W);
+  kp2d_model* mm = const_cast<kp2d_model*>(m);
+  // size for the largest lane count this handle may use (profiling toggles lanes to 1, which needs less)
+  const bool prof = mm->profiling;
+  mm->profiling = false;
+  int nl, chunk;
+  schedule(m, B, H, W, &nl, &chunk);
+  mm->profiling = prof;
+  const size_t per = align_up(plan_bytes(mm, chunk, H, W));
+  int nl1, chunk1;
+  mm->profiling = true;
+  schedule(m, B, H, W, &nl1, &chunk1);
+  mm->profiling = prof;
+  return std::max(per * nl, align_up(plan_bytes(mm, chunk1, H, W)));
 }
 
 int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
@@ -912,20 +962,38 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
   int rc = validate_shape(m, B, H, W);
   if (rc != KP2D_OK) return rc;
   if ((uintptr_t)workspace % ALIGN) return fail(KP2D_ERR_WORKSPACE, "workspace must be %zu-byte aligned", ALIGN);
-  const int chunk = auto_chunk(m, B, H, W);
-  const size_t need = plan_bytes(m, chunk, H, W);
-  if (need == 0) return KP2D_ERR_WORKSPACE;
-  if (workspace_bytes < need) return fail(KP2D_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  int nl, chunk;
+  schedule(m, B, H, W, &nl, &chunk);
+  const size_t per = align_up(plan_bytes(m, chunk, H, W));
+  if (per == 0) return KP2D_ERR_WORKSPACE;
+  if (workspace_bytes < per * nl) return fail(KP2D_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, per * nl);
   const kp2d_config& g = m->cfg;
   const size_t Hc = H / 4, Wc = W / 4, H2 = H / 2, W2 = W / 2;
+  hipStream_t caller = (hipStream_t)stream;
   m->prof_used = 0;
-  m->prof_stream = (hipStream_t)stream;
-  for (int b0 = 0; b0 < B; b0 += chunk) {
+  m->prof_stream = caller;
+  // fork: lanes 1.. run on internal streams that start after everything already queued on the caller's stream
+  if (nl > 1) {
+    HIP_TRY(hipSetDevice(g.device));
+    while ((int)m->lane_streams.size() < nl - 1) {
+      hipStream_t st; hipEvent_t ev;
+      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      m->lane_streams.push_back(st); m->lane_events.push_back(ev);
+    }
+    if (!m->fork_event) HIP_TRY(hipEventCreateWithFlags(&m->fork_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->fork_event, caller));
+    for (int k = 1; k < nl; ++k) HIP_TRY(hipStreamWaitEvent(m->lane_streams[k - 1], m->fork_event, 0));
+  }
+  int ci = 0;
+  for (int b0 = 0; b0 < B; b0 += chunk, ++ci) {
+    const int lane = ci % nl;
     Plan P{};
-    P.m = m; P.stream = (hipStream_t)stream; P.ws = (char*)workspace; P.dry = false;
+    P.m = m; P.stream = lane == 0 ? caller : m->lane_streams[lane - 1];
+    P.ws = (char*)workspace + (size_t)lane * per; P.dry = false;
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W;
-    P.s16_mode = m->precision == KP2D_PREC_F16X3 && m->s16_ok && !m->no_dma;
-    P.arena.reset(workspace_bytes);
+    P.s16_mode = m->precision == KP2D_PREC_F16X3 && m->s16_ok && !m->no_s16;
+    P.arena.reset(per);
     FwdOut o{};
     o.x = x + (size_t)b0 * 3 * H * W;
     o.score = score + (size_t)b0 * Hc * Wc;
@@ -935,6 +1003,11 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     o.vlad = vlad + (size_t)b0 * g.num_clusters * g.encoder_dim;
     build(P, o, flags);
     if (P.rc != KP2D_OK) return P.rc;
+  }
+  // join: the caller's stream continues only after every lane has drained
+  for (int k = 1; k < nl; ++k) {
+    HIP_TRY(hipEventRecord(m->lane_events[k - 1], m->lane_streams[k - 1]));
+    HIP_TRY(hipStreamWaitEvent(caller, m->lane_events[k - 1], 0));
   }
   return KP2D_OK;
 }

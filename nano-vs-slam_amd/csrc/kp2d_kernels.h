@@ -34,6 +34,7 @@ struct ConvSrc { const float* p; int c, o; long bs, rs, ps; };   // channels tak
 struct ConvArgs {
   ConvSrc in0, in1;
   int taps;                           // 9 or 1
+  int in_s16;                         // sources are in the pre-split S16 format (f16x3 mode only)
   int prec;                           // 0: exact fp32 MFMA, 1: split-fp16 3xMFMA (weights packed as hi|lo halves)
   const float* w;                     // packed [group][cin_pad/KC][taps][ng][KC]
   const float* scale;                 // [npad]  BN: gamma/sqrt(var+eps); bias conv: 1
@@ -45,6 +46,7 @@ struct ConvArgs {
   int cin, cout, npad;
   int act, store, nsplit;
   int tiles_x, tiles_y;
+  int dbg;                            // timing ablations only (KP2D_DBG): 1 skip stores, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA
 };
 
 struct Conv1aArgs {                   // backbone.conv1a: NCHW RGB in -> NHWC out, Cin = 3
