@@ -111,6 +111,17 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
 int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
                           float* pts, float* dsel, void* stream);
 
+/* replaces: BfFeatureMatcher.match = cv2.BFMatcher(NORM_L2).knnMatch(k=2) + goodMatchesOneToOne
+ * (src/visual_odometry/feature_matcher.py:89-98, :179-209), batched over B frame pairs, on device.
+ *   d0 [B,max0,C] query descriptors, n0 [B] valid rows; d1 [B,max1,C] train descriptors, n1 [B]; C in {32,64}
+ *   nn_idx / nn_dist / nn_dist2 [B,max0]  nearest train row, its L2 distance, second-nearest distance
+ *   match_q [B,max1]  the query kept for each train row after ratio test + one-to-one filtering (-1: none)
+ *   match_d [B,max1]  its distance
+ *   scratch: B*max1*8 bytes of device memory */
+int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
+                           int max1, int C, float ratio, int32_t* nn_idx, float* nn_dist, float* nn_dist2,
+                           int32_t* match_q, float* match_d, void* scratch, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* when on, every kernel launch of kp2d_forward is bracketed by HIP events on the caller's stream */
 int kp2d_set_profiling(kp2d_model* m, int on);

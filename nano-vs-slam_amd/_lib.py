@@ -60,6 +60,7 @@ SIGNATURES = {
     "kp2d_post": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 11 + [_P, _P, _P, _P, _P]),
     "kp2d_select_topk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),
     "kp2d_gather_keypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "kp2d_match_descriptors": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "kp2d_set_profiling": (C.c_int, [_P, C.c_int]),
     "kp2d_profile_count": (C.c_int, [_P]),
     "kp2d_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _F,

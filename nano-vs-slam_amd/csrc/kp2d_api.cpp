@@ -1053,6 +1053,19 @@ int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* 
   return KP2D_OK;
 }
 
+int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
+                           int max1, int C, float ratio, int32_t* nn_idx, float* nn_dist, float* nn_dist2,
+                           int32_t* match_q, float* match_d, void* scratch, void* stream) {
+  if (!d0 || !n0 || !d1 || !n1 || !nn_idx || !nn_dist || !nn_dist2 || !match_q || !match_d || !scratch)
+    return fail(KP2D_ERR_ARG, "null argument");
+  if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
+  MatchArgs a{d0, d1, n0, n1, B, max0, max1, C, ratio, nn_idx, nn_dist, nn_dist2,
+              reinterpret_cast<unsigned long long*>(scratch), match_q, match_d};
+  int e = launch_match(a, (hipStream_t)stream);
+  if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "match kernels: %d (descriptor width %d)", e, C);
+  return KP2D_OK;
+}
+
 int kp2d_set_profiling(kp2d_model* m, int on) {
   if (!m) return fail(KP2D_ERR_ARG, "null model");
   m->profiling = on != 0;

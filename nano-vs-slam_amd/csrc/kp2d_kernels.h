@@ -122,6 +122,18 @@ struct AttnArgs {
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
+// ---- descriptor matching (src/visual_odometry/feature_matcher.py:89-98, 179-209) ---------------
+struct MatchArgs {
+  const float* d0; const float* d1;         // [B][max0][C] query / [B][max1][C] train descriptors
+  const int32_t* n0; const int32_t* n1;     // [B] valid rows per pair
+  int B, max0, max1, C;
+  float ratio;
+  int32_t* nn_idx; float* nn_dist; float* nn_dist2;   // [B][max0] k=2 neighbours of every query
+  unsigned long long* train_best;                      // [B][max1] scratch: (distance bits << 32 | query)
+  int32_t* match_q; float* match_d;                    // [B][max1] query matched to each train row (-1: none)
+};
+int launch_match(const MatchArgs& a, hipStream_t s);
+
 // ---- small layout / elementwise kernels -----------------------------------------------------
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s);
 

@@ -572,5 +572,27 @@ def select_k3(score, coord, feat, k=1024):
     return order, s[bi, order], pts[bi, order], d[bi, order]
 
 
+def bf_match_one_to_one(des1, des2, ratio=0.7):
+    """BfFeatureMatcher.match — src/visual_odometry/feature_matcher.py:89-98 (cv2.BFMatcher(NORM_L2).knnMatch
+    k=2, restated: L2 distance = sqrt(sum (a-b)^2), neighbours sorted by distance) + goodMatchesOneToOne
+    :179-209 (skip if m.distance > ratio * n.distance; each trainIdx keeps the smallest distance, the earlier
+    query on ties).  Returns ({trainIdx: (queryIdx, distance)}, nn_idx, nn_dist, nn_dist2)."""
+    des1 = np.asarray(des1, np.float32)
+    des2 = np.asarray(des2, np.float32)
+    d = np.sqrt(((des1[:, None, :] - des2[None, :, :]) ** 2).sum(-1, dtype=np.float32))
+    order = np.argsort(d, axis=1, kind="stable")
+    nn = order[:, 0]
+    d1 = d[np.arange(len(des1)), nn]
+    d2 = d[np.arange(len(des1)), order[:, 1]] if des2.shape[0] > 1 else np.full(len(des1), np.inf, np.float32)
+    best = {}
+    for q in range(len(des1)):
+        if d1[q] > np.float32(ratio) * d2[q]:
+            continue
+        t = int(nn[q])
+        if t not in best or d1[q] < best[t][1]:
+            best[t] = (q, float(d1[q]))
+    return best, nn, d1, d2
+
+
 def cast_params(p, dtype):
     return {k: (v.astype(dtype) if v.dtype.kind == "f" else v) for k, v in p.items()}

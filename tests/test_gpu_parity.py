@@ -267,3 +267,42 @@ def test_inference_front_end_matches_oracle():
     rorder = np.lexsort((rpts[:, 0], rpts[:, 1]))
     assert np.max(np.abs(pts[order] - rpts[rorder])) < 1e-3
     assert np.max(np.abs(feat[order] - rdesc[rorder])) < 1e-3
+
+
+def test_descriptor_matching_against_oracle():
+    """kp2d_match_descriptors vs the restated BfFeatureMatcher (knnMatch k=2 + goodMatchesOneToOne)."""
+    from nano_vs_slam_amd.matching import bf_match, match_descriptors
+    rng = np.random.default_rng(12)
+    B, k0, k1, C = 3, 700, 900, 32
+    d0 = rng.standard_normal((B, k0, C)).astype(np.float32)
+    d1 = rng.standard_normal((B, k1, C)).astype(np.float32)
+    # make real correspondences (noisy copies) plus exact duplicates so the one-to-one rule is exercised
+    for b in range(B):
+        src = rng.permutation(k1)[:400]
+        d0[b, :400] = d1[b, src] + 0.05 * rng.standard_normal((400, C)).astype(np.float32)
+        d0[b, 400:420] = d0[b, :20]
+    d0 /= np.linalg.norm(d0, axis=-1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
+    n0 = np.array([700, 650, 1], np.int32)
+    n1 = np.array([900, 2, 900], np.int32)
+    r = match_descriptors(torch.from_numpy(d0).to(DEV), torch.from_numpy(n0).to(DEV), torch.from_numpy(d1).to(DEV),
+                          torch.from_numpy(n1).to(DEV), 0.7)
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    for b in range(B):
+        best, nn, dd1, dd2 = orc.bf_match_one_to_one(d0[b, :n0[b]], d1[b, :n1[b]], 0.7)
+        assert np.array_equal(r["nn_idx"][b, :n0[b]], nn)
+        assert np.max(np.abs(r["nn_dist"][b, :n0[b]] - dd1)) < 1e-5
+        fin = np.isfinite(dd2)
+        assert np.max(np.abs(r["nn_dist2"][b, :n0[b]][fin] - dd2[fin]), initial=0) < 1e-5
+        got = {int(t): int(q) for t, q in enumerate(r["match_q"][b]) if q >= 0}
+        ref = {t: q for t, (q, _) in best.items()}
+        # pairs may differ only where the ratio test sits on its boundary (two fp32 roundings of the distance)
+        for t in set(got) ^ set(ref):
+            q = got.get(t, ref.get(t))
+            assert abs(dd1[q] - 0.7 * dd2[q]) < 1e-5
+        assert all(got[t] == ref[t] for t in set(got) & set(ref))
+        assert np.all(r["match_q"][b, n1[b]:] == -1)
+        assert len(got) > 100 or b > 0
+    i1, i2, sc = bf_match(d0[0], d1[0], 0.7)
+    best, *_ = orc.bf_match_one_to_one(d0[0], d1[0], 0.7)
+    assert {t: q for q, t in zip(i1, i2)} == {t: q for t, (q, _) in best.items()}
