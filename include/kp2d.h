@@ -55,7 +55,12 @@ typedef struct kp2d_config {
   int32_t leaky_relu;       /* 1: LeakyReLU(0.01), 0: ReLU                                               */
   int32_t remove_softmax;   /* V3 only (kp2dtiny.py:698,942)                                             */
   int32_t device;           /* HIP device ordinal                                                        */
+  int32_t global_descriptor;/* KP2D_GD_NETVLAD / KP2D_GD_GEM / KP2D_GD_CONVAP (vpr.py:53-76)                     */
+  int32_t remove_netvlad;   /* to_export configs: "vlad" is the encoder map [B,enc,H/4,W/4] (vpr.py:84)          */
 } kp2d_config;
+#define KP2D_GD_NETVLAD 0
+#define KP2D_GD_GEM 1
+#define KP2D_GD_CONVAP 2
 
 /* kp2d_forward flags */
 #define KP2D_FWD_EVAL 1u    /* model.training is False: V3 applies Softmax2d to seg (kp2dtiny.py:942-943) */
@@ -89,7 +94,8 @@ size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W);
  *   x      [B,3,H,W]  RGB in [-1,1]; H, W divisible by 8
  *   score  [B,1,H/4,W/4]  sigmoid, un-bordered      shift [B,2,H/4,W/4]  tanh ("coord" key of forward)
  *   feat   [B,nfeatures,H/2,W/2] dense descriptors   seg   [B,n_classes,H/2,W/2] logits (V3 eval: probabilities)
- *   vlad   [B,num_clusters*encoder_dim] */
+ *   vlad   [B,kp2d_vlad_dim]: NetVLAD K*C; GeM / ConvAP encoder_dim*16; remove_netvlad: [B,encoder_dim,H/4,W/4] */
+size_t kp2d_vlad_dim(const kp2d_model* m, int H, int W);
 int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
                  float* feat, float* seg, float* vlad, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -99,7 +105,9 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
  *   desc [B,C,Hc,Wc] bilinearly sampled, unit norm   seg_ids [B,1,Hs,Ws] int64 argmax over seg's channels */
 int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,
               int H, int W, int Hc, int Wc, int feat_c, int Hf, int Wf, int seg_c, int Hs, int Ws, float* score_out,
-              float* coord, float* desc, int64_t* seg_ids, void* stream);
+              float* coord, float* desc, int64_t* seg_ids, int sample_segmentation, void* stream);
+/* sample_segmentation != 0 (model.sample_segmentation, kp2dtiny.py:634-639): seg_ids is [B,1,Hc,Wc], the class of the
+ * nearest seg pixel at each cell's coordinate, instead of the dense [B,1,Hs,Ws] argmax. */
 
 /* replaces the callers' selectors: threshold + top-k on the cell grid, batched and on device
  * (evaluation/visual_odometry.py:105-117 K1, evaluation/descriptor.py:12-36 K2,

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libkp2d_hip.so")
 
 KP2D_FWD_EVAL = 1
 PRECISIONS = {"fp32": 0, "f16x3": 1}
+GLOBAL_DESCRIPTORS = {"netvlad": 0, "gem": 1, "convap": 2}
 
 
 class Kp2dConfig(C.Structure):
@@ -32,6 +33,8 @@ class Kp2dConfig(C.Structure):
         ("leaky_relu", C.c_int32),
         ("remove_softmax", C.c_int32),
         ("device", C.c_int32),
+        ("global_descriptor", C.c_int32),
+        ("remove_netvlad", C.c_int32),
     ]
 
 
@@ -57,7 +60,8 @@ SIGNATURES = {
     "kp2d_import_packed": (C.c_int, [_P, _P, _P]),
     "kp2d_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     "kp2d_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "kp2d_post": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 11 + [_P, _P, _P, _P, _P]),
+    "kp2d_post": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 11 + [_P, _P, _P, _P, C.c_int, _P]),
+    "kp2d_vlad_dim": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "kp2d_select_topk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),
     "kp2d_gather_keypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "kp2d_match_descriptors": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P]),

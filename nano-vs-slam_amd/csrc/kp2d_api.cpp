@@ -278,8 +278,16 @@ int describe(kp2d_model* m) {
   add_cbr(m, "vlad_head.convlad1", c4, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad2", g.encoder_dim, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad3", g.encoder_dim, g.encoder_dim);
-  add_spec(m, "vlad_head.netvlad.centroids", {g.num_clusters, g.encoder_dim});
-  add_spec(m, "vlad_head.netvlad.conv.weight", {g.num_clusters, g.encoder_dim, 1, 1});
+  const bool has_vlad = g.global_descriptor == KP2D_GD_NETVLAD && !g.remove_netvlad;
+  if (has_vlad) {
+    add_spec(m, "vlad_head.netvlad.centroids", {g.num_clusters, g.encoder_dim});
+    add_spec(m, "vlad_head.netvlad.conv.weight", {g.num_clusters, g.encoder_dim, 1, 1});
+  } else if (g.global_descriptor == KP2D_GD_GEM) {
+    add_spec(m, "vlad_head.netvlad.p", {1});
+    m->vecs["vlad_head.netvlad.p"].n = 1;
+  } else if (g.global_descriptor == KP2D_GD_CONVAP) {
+    add_pw(m, "vlad_head.netvlad.channel_pool", g.encoder_dim, g.encoder_dim, true, 1);
+  }
 
   // blob layout
   size_t off = 0;
@@ -300,8 +308,10 @@ int describe(kp2d_model* m) {
     if (c.s16_capable()) c.w16s_off = take(c.w16_floats());
   }
   for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
-  m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
-  m->vlad_cent = take((size_t)g.num_clusters * g.encoder_dim);
+  if (has_vlad) {
+    m->vlad_wa = take((size_t)g.num_clusters * g.encoder_dim);
+    m->vlad_cent = take((size_t)g.num_clusters * g.encoder_dim);
+  }
   m->blob_floats = off;
   return KP2D_OK;
 }
@@ -428,10 +438,12 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
       std::copy(src.begin(), src.end(), blob.begin() + kv.second.off);
     }
   }
-  const auto& wa = *host_get(m, "vlad_head.netvlad.conv.weight");
-  const auto& ce = *host_get(m, "vlad_head.netvlad.centroids");
-  std::copy(wa.begin(), wa.end(), blob.begin() + m->vlad_wa);
-  std::copy(ce.begin(), ce.end(), blob.begin() + m->vlad_cent);
+  if (m->cfg.global_descriptor == KP2D_GD_NETVLAD && !m->cfg.remove_netvlad) {
+    const auto& wa = *host_get(m, "vlad_head.netvlad.conv.weight");
+    const auto& ce = *host_get(m, "vlad_head.netvlad.centroids");
+    std::copy(wa.begin(), wa.end(), blob.begin() + m->vlad_wa);
+    std::copy(ce.begin(), ce.end(), blob.begin() + m->vlad_cent);
+  }
   return KP2D_OK;
 }
 
@@ -761,20 +773,42 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // NetVLAD reads fp32
     P.release(v2);
     const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
-    const int ns = netvlad_nsplit(S);
-    Act part{};
-    part.bytes = (size_t)B * ns * ((size_t)K * C + K) * sizeof(float);
-    part.off = P.arena.alloc(part.bytes);
-    if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
-    if (!P.dry && P.rc == KP2D_OK) {
-      VladArgs a{};
-      a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
-      a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns;
-      P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
-      P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
-      P.prof_end();
+    if (g.global_descriptor == KP2D_GD_GEM) {
+      if (!P.dry && P.rc == KP2D_OK) {
+        PoolArgs a{P.ptr(v3a), m->blob + m->vecs.at("vlad_head.netvlad.p").off, o.vlad, B, C, Hc, Wc};
+        P.prof_begin("vlad_head.netvlad", "gem", 4.0 * B * S * C, 4.0 * B * S * C);
+        P.check(launch_gem(a, P.stream), "vlad_head.netvlad (GeM)");
+        P.prof_end();
+      }
+    } else if (g.global_descriptor == KP2D_GD_CONVAP) {
+      Act cp = P.pw("vlad_head.netvlad.channel_pool", v3a, ACT_NONE);
+      if (!P.dry && P.rc == KP2D_OK) {
+        PoolArgs a{P.ptr(cp), nullptr, o.vlad, B, C, Hc, Wc};
+        P.prof_begin("vlad_head.netvlad", "convap_pool", 1.0 * B * S * C, 4.0 * B * S * C);
+        P.check(launch_convap_pool(a, P.stream), "vlad_head.netvlad (ConvAP)");
+        P.prof_end();
+      }
+      P.release(cp);
+    } else if (g.remove_netvlad) {
+      // to_export: the reference returns the encoder map itself (vpr.py:84), NCHW
+      if (!P.dry && P.rc == KP2D_OK)
+        P.check(launch_nhwc_to_nchw(P.ptr(v3a), o.vlad, B, C, S, C, 0, P.stream), "vlad_head (encoder map)");
+    } else {
+      const int ns = netvlad_nsplit(S);
+      Act part{};
+      part.bytes = (size_t)B * ns * ((size_t)K * C + K) * sizeof(float);
+      part.off = P.arena.alloc(part.bytes);
+      if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
+      if (!P.dry && P.rc == KP2D_OK) {
+        VladArgs a{};
+        a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
+        a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns;
+        P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
+        P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
+        P.prof_end();
+      }
+      P.arena.release(part.off, part.bytes);
     }
-    P.arena.release(part.off, part.bytes);
     P.release(v3a);
   }
   P.release(xb);
@@ -834,6 +868,7 @@ int32_t kp2d_abi_version(void) { return KP2D_ABI_VERSION; }
 int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   if (!cfg || !out) return fail(KP2D_ERR_ARG, "null argument");
   if (cfg->struct_size != (int32_t)sizeof(kp2d_config)) return fail(KP2D_ERR_ARG, "kp2d_config.struct_size mismatch");
+  if (cfg->global_descriptor < KP2D_GD_NETVLAD || cfg->global_descriptor > KP2D_GD_CONVAP) return fail(KP2D_ERR_ARG, "bad global_descriptor");
   if (cfg->version != 2 && cfg->version != 3) return fail(KP2D_ERR_ARG, "version must be 2 or 3");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -938,6 +973,14 @@ static void schedule(const kp2d_model* m, int B, int H, int W, int* lanes, int* 
   *chunk = std::max(1, c);
 }
 
+size_t kp2d_vlad_dim(const kp2d_model* m, int H, int W) {
+  if (!m) return 0;
+  const kp2d_config& g = m->cfg;
+  if (g.global_descriptor != KP2D_GD_NETVLAD) return (size_t)g.encoder_dim * 16;
+  if (g.remove_netvlad) return (size_t)g.encoder_dim * (H / 4) * (W / 4);
+  return (size_t)g.num_clusters * g.encoder_dim;
+}
+
 size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
   if (!m || validate_shape(m, B, H, W) != KP2D_OK) return 0;
   kp2d_model* mm = const_cast<kp2d_model*>(m);
@@ -1000,7 +1043,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     o.shift = shift + (size_t)b0 * 2 * Hc * Wc;
     o.feat = feat + (size_t)b0 * g.nfeatures * H2 * W2;
     o.seg = seg + (size_t)b0 * g.n_classes * H2 * W2;
-    o.vlad = vlad + (size_t)b0 * g.num_clusters * g.encoder_dim;
+    o.vlad = vlad + (size_t)b0 * kp2d_vlad_dim(m, H, W);
     build(P, o, flags);
     if (P.rc != KP2D_OK) return P.rc;
   }
@@ -1014,7 +1057,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
 
 int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,
               int H, int W, int Hc, int Wc, int feat_c, int Hf, int Wf, int seg_c, int Hs, int Ws, float* score_out,
-              float* coord, float* desc, int64_t* seg_ids, void* stream) {
+              float* coord, float* desc, int64_t* seg_ids, int sample_segmentation, void* stream) {
   if (!m || !score || !shift || !score_out || !coord) return fail(KP2D_ERR_ARG, "null argument");
   if (desc && !feat) return fail(KP2D_ERR_ARG, "desc requested without feat");
   if (seg_ids && !seg) return fail(KP2D_ERR_ARG, "seg_ids requested without seg");
@@ -1026,7 +1069,11 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
   if (!desc) a.C = 32;
   int e = launch_post(a, (hipStream_t)stream);
   if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "post kernel: %d (descriptor channels %d)", e, feat_c);
-  if (seg_ids) {
+  if (seg_ids && sample_segmentation) {
+    SegSampleArgs g{seg, coord, seg_ids, B, seg_c, Hs, Ws, Hc, Wc, H, W};
+    e = launch_seg_sample_argmax(g, (hipStream_t)stream);
+    if (e) return fail(KP2D_ERR_HIP, "sampled argmax kernel: %d", e);
+  } else if (seg_ids) {
     ArgmaxArgs g{seg, seg_ids, B, seg_c, Hs * Ws};
     e = launch_seg_argmax(g, (hipStream_t)stream);
     if (e) return fail(KP2D_ERR_HIP, "argmax kernel: %d", e);

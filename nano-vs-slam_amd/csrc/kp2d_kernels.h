@@ -71,6 +71,9 @@ struct VladArgs {
   int B, S, C, K, nsplit;
 };
 int launch_netvlad(const VladArgs& a, hipStream_t s);
+struct PoolArgs { const float* x; const float* p; float* out; int B, C, Hc, Wc; };   // GeM (p = exponent) / ConvAP pooling
+int launch_gem(const PoolArgs& a, hipStream_t s);
+int launch_convap_pool(const PoolArgs& a, hipStream_t s);
 int netvlad_nsplit(int S);
 
 // ---- post-processing (models/kp2dtiny.py:593-647 / 959-1015) -------------------------------
@@ -88,6 +91,8 @@ int launch_post(const PostArgs& a, hipStream_t s);
 
 struct ArgmaxArgs { const float* seg; int64_t* ids; int B, C, HW; };
 int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s);
+struct SegSampleArgs { const float* seg; const float* coord; int64_t* ids; int B, C, Hs, Ws, Hc, Wc, H, W; };
+int launch_seg_sample_argmax(const SegSampleArgs& a, hipStream_t s);
 
 // ---- keypoint selection (callers K1/K2/K3) ----------------------------------
 struct TopkArgs {

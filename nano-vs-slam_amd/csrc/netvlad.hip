@@ -287,6 +287,63 @@ __global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
   for (int e = tid; e < KC_; e += 256) a.out[(size_t)b * KC_ + e] = s_v[e] * inv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Config-selectable poolers
+// GeM (modules/aggregators/gem.py:21-31): PixelUnshuffle(4) -> clamp(min=1e-6)^p -> global mean -> ^(1/p);
+//   output index = c*16 + i*4 + j for input channel c and sub-position (i, j) = (y & 3, x & 3).
+// ConvAP (modules/aggregators/convap.py:28-34): [1x1 conv + bias runs in conv3x3.hip] -> AdaptiveAvgPool2d((4,4))
+//   -> flatten (c*16 + a*4 + b) -> L2 normalise (eps 1e-12).
+// One workgroup per frame; x is the NHWC encoder map [S = Hc*Wc][C].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gem_kernel(const PoolArgs a) {
+  const int b = blockIdx.x, C = a.C, Hc = a.Hc, Wc = a.Wc;
+  const float p = a.p[0], eps = 1e-6f;
+  const float* x = a.x + (size_t)b * Hc * Wc * C;
+  const float inv = 1.f / (float)((Hc >> 2) * (Wc >> 2));
+  for (int o = threadIdx.x; o < C * 16; o += 256) {
+    const int c = o >> 4, i = (o >> 2) & 3, j = o & 3;
+    float acc = 0.f;
+    for (int y = i; y < Hc; y += 4)
+      for (int xx = j; xx < Wc; xx += 4) acc += powf(fmaxf(x[((size_t)y * Wc + xx) * C + c], eps), p);
+    a.out[(size_t)b * C * 16 + o] = powf(acc * inv, 1.f / p);
+  }
+}
+
+__global__ __launch_bounds__(256) void convap_pool_kernel(const PoolArgs a) {
+  extern __shared__ float sm[];          // [C*16] pooled values + [4] wave sums
+  const int b = blockIdx.x, C = a.C, Hc = a.Hc, Wc = a.Wc;
+  const float* x = a.x + (size_t)b * Hc * Wc * C;
+  float ss = 0.f;
+  for (int o = threadIdx.x; o < C * 16; o += 256) {
+    const int c = o >> 4, aa = (o >> 2) & 3, bb = o & 3;
+    const int y0 = (aa * Hc) / 4, y1 = ((aa + 1) * Hc + 3) / 4;      // floor / ceil bin edges (AdaptiveAvgPool2d)
+    const int x0 = (bb * Wc) / 4, x1 = ((bb + 1) * Wc + 3) / 4;
+    float acc = 0.f;
+    for (int y = y0; y < y1; ++y)
+      for (int xx = x0; xx < x1; ++xx) acc += x[((size_t)y * Wc + xx) * C + c];
+    const float v = acc / (float)((y1 - y0) * (x1 - x0));
+    sm[o] = v;
+    ss = fmaf(v, v, ss);
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) sm[C * 16 + (threadIdx.x >> 6)] = ss;
+  __syncthreads();
+  const float* w = &sm[C * 16];
+  const float inv = 1.f / fmaxf(sqrtf(w[0] + w[1] + w[2] + w[3]), 1e-12f);
+  for (int o = threadIdx.x; o < C * 16; o += 256) a.out[(size_t)b * C * 16 + o] = sm[o] * inv;
+}
+
+int launch_gem(const PoolArgs& a, hipStream_t s) {
+  if ((a.Hc & 3) || (a.Wc & 3)) return -1600;     // PixelUnshuffle(4) needs divisible spatial dims (torch raises too)
+  hipLaunchKernelGGL(gem_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_convap_pool(const PoolArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(convap_pool_kernel, dim3(a.B), dim3(256), (size_t)(a.C * 16 + 4) * sizeof(float), s, a);
+  return (int)hipGetLastError();
+}
+
 int launch_netvlad(const VladArgs& a, hipStream_t s) {
   if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 4096 || a.K < 4) return -1100;
   if ((a.K == 32 || a.K == 64) && a.C <= 64) {

@@ -104,6 +104,35 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(const ArgmaxArgs a) {
   a.ids[(size_t)b * a.HW + p] = (int64_t)bi;
 }
 
+// sample_seg with sample_segmentation=True (models/kp2dtiny.py:634-639): nearest-neighbour grid_sample of the
+// class map at every cell's predicted coordinate (align_corners=True, zeros outside), then argmax.
+__global__ __launch_bounds__(256) void seg_sample_argmax_kernel(const SegSampleArgs a) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, ncell = a.Hc * a.Wc;
+  if (cell >= ncell) return;
+  const float cx = a.coord[((size_t)b * 2 + 0) * ncell + cell], cy = a.coord[((size_t)b * 2 + 1) * ncell + cell];
+  const float gx = __fsub_rn(__fdiv_rn(cx, (float)(a.W - 1) * 0.5f), 1.f);
+  const float gy = __fsub_rn(__fdiv_rn(cy, (float)(a.H - 1) * 0.5f), 1.f);
+  const float ix = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(a.Ws - 1));
+  const float iy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(a.Hs - 1));
+  const int x = (int)nearbyintf(ix), y = (int)nearbyintf(iy);       // round half to even, as torch's nearest mode
+  const bool ok = x >= 0 && x < a.Ws && y >= 0 && y < a.Hs;
+  const size_t plane = (size_t)a.Hs * a.Ws;
+  const float* sp = a.seg + (size_t)b * a.C * plane + (ok ? (size_t)y * a.Ws + x : 0);
+  float best = ok ? sp[0] : 0.f;
+  int bi = 0;
+  for (int c = 1; c < a.C; ++c) {
+    const float v = ok ? sp[c * plane] : 0.f;
+    if (v > best) { best = v; bi = c; }
+  }
+  a.ids[(size_t)b * ncell + cell] = (int64_t)bi;
+}
+
+int launch_seg_sample_argmax(const SegSampleArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(seg_sample_argmax_kernel, dim3((a.Hc * a.Wc + 255) / 256, a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(seg_argmax_kernel, dim3((a.HW + 255) / 256, a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();

@@ -210,12 +210,42 @@ class _NetVLAD(_Holder):
         self.centroids = nn.Parameter(torch.rand(num_clusters, dim))
 
 
+class _GeM(_Holder):
+    """Parameters of GeM (reference modules/aggregators/gem.py:7-19)."""
+
+    def __init__(self, p=3.0):
+        super().__init__()
+        self.p = nn.Parameter(torch.ones(1) * p)
+
+
+class _ConvAP(_Holder):
+    """Parameters of ConvAP (reference modules/aggregators/convap.py:19-26)."""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.channel_pool = nn.Conv2d(c_in, c_out, kernel_size=1, bias=True)
+
+
 class _VPRHead(_Holder):
-    def __init__(self, c_in, enc, num_clusters, mom):
+    """Parameters of VPRHead (reference modules/decoders/vpr.py:8-76): pooler chosen by ``method``."""
+
+    def __init__(self, c_in, enc, num_clusters, mom, method="netvlad", remove_netvlad=False):
         super().__init__()
         self.convlad1, self.convlad2, self.convlad3 = _CBR(c_in, enc, mom), _CBR(enc, enc, mom), _CBR(enc, enc, mom)
-        self.netvlad = _NetVLAD(num_clusters, enc)
-        self.global_desc_dim = num_clusters * enc
+        if method == "netvlad":
+            if not remove_netvlad:
+                self.netvlad = _NetVLAD(num_clusters, enc)     # NetVLADMemoryEfficient computes the same function
+                self.global_desc_dim = num_clusters * enc
+            else:
+                self.global_desc_dim = 0
+        elif method == "gem":
+            self.netvlad = _GeM()
+            self.global_desc_dim = enc * 16
+        elif method == "convap":
+            self.netvlad = _ConvAP(enc, enc)
+            self.global_desc_dim = enc * 16
+        else:
+            raise ValueError(f"unknown global_descriptor_method {method!r}")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -288,20 +318,16 @@ class _KP2DTinyBase(nn.Module):
         cfg.use_attention, cfg.leaky_relu = int(bool(self.use_attention)), int(bool(self.leaky_relu))
         cfg.remove_softmax = int(bool(getattr(self, "remove_softmax", False)))
         cfg.device = device_index
+        cfg.global_descriptor = _lib.GLOBAL_DESCRIPTORS[self.global_descriptor_method]
+        cfg.remove_netvlad = int(bool(self.remove_netvlad))
         return cfg
 
     def _check_built(self):
         why = None
         if self.upscale_method != "pixelshuffle":
             why = f"upscale_method={self.upscale_method!r} (to_mcu path)"
-        elif self.global_descriptor_method != "netvlad":
-            why = f"global_descriptor_method={self.global_descriptor_method!r}"
-        elif self.remove_netvlad:
-            why = "remove_netvlad=True (to_export path)"
         elif self.depth:
             why = "depth=True"
-        elif getattr(self, "mem_efficient", False):
-            why = "mem_efficient=True (NetVLADMemoryEfficient)"
         if why:
             raise NotImplementedError(f"{why} is outside the path built so far (DESIGN.md, 'out of scope / next')")
 
@@ -385,7 +411,9 @@ class _KP2DTinyBase(nn.Module):
         shift = torch.empty(B, 2, Hc, Wc, device=dev)
         feat = torch.empty(B, self.nfeatures, H2, W2, device=dev)
         seg = torch.empty(B, self.nClasses, H2, W2, device=dev)
-        vlad = torch.empty(B, self.global_desc_dim, device=dev)
+        vdim = eng.lib.kp2d_vlad_dim(eng.handle, H, W)
+        vlad = (torch.empty(B, self.encoder_dim, Hc, Wc, device=dev) if self.remove_netvlad and
+                self.global_descriptor_method == "netvlad" else torch.empty(B, vdim, device=dev))
         ws = eng.workspace(B, H, W, dev)
         flags = 0 if self.training else _lib.KP2D_FWD_EVAL
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -403,8 +431,6 @@ class _KP2DTinyBase(nn.Module):
         B, _, Hc, Wc = score.shape
         dev = score.device
         sample = self.training is False
-        if sample and self.sample_segmentation:
-            raise NotImplementedError("sample_segmentation=True (nearest grid_sample of seg) is not built yet")
         score_out = torch.empty_like(score)
         coord = torch.empty_like(shift)
         desc = seg_ids = seg = None
@@ -414,11 +440,12 @@ class _KP2DTinyBase(nn.Module):
             seg = out["seg"].contiguous()
             sc, Hs, Ws = seg.shape[1], seg.shape[2], seg.shape[3]
             desc = torch.empty(B, fc, Hc, Wc, device=dev)
-            seg_ids = torch.empty(B, 1, Hs, Ws, dtype=torch.int64, device=dev)
+            seg_ids = (torch.empty(B, 1, Hc, Wc, dtype=torch.int64, device=dev) if self.sample_segmentation
+                       else torch.empty(B, 1, Hs, Ws, dtype=torch.int64, device=dev))
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(eng.lib.kp2d_post(eng.handle, _ptr(score), _ptr(shift), _ptr(feat), _ptr(seg), B, int(H), int(W),
                                      Hc, Wc, fc, Hf, Wf, sc, Hs, Ws, _ptr(score_out), _ptr(coord), _ptr(desc),
-                                     _ptr(seg_ids), C.c_void_p(stream)))
+                                     _ptr(seg_ids), int(bool(self.sample_segmentation)), C.c_void_p(stream)))
         if sample:
             out["seg"] = seg_ids
             feat = desc
@@ -507,7 +534,7 @@ class KP2DTinyV2(_KP2DTinyBase):
         self.loc_head = _SimpleTaskHead(c4, c4, 2, mom)
         self.desc_head = _UpscaleHead(c4, c4, c3 * 4, c3 + c4, c4, nfeatures, mom)
         self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention)
-        self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom)
+        self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # reference force-sets this (kp2dtiny.py:456)
         self.global_desc_dim = self.vlad_head.global_desc_dim
@@ -539,7 +566,7 @@ class KP2DTinyV3(_KP2DTinyBase):
         self.backbone = _BackBone(3, c1, c2, c3, c4, 0.1)
         self.score_loc_head = _SimpleTaskHead(c4, c4, 3, mom)
         self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures)
-        self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom)
+        self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # kp2dtiny.py:813
         self.global_desc_dim = self.vlad_head.global_desc_dim

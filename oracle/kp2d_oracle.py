@@ -34,6 +34,9 @@ V2_CONFIGS = {
     "S_A": dict(_S, use_attention=True),
     "N": dict(_N, use_attention=False),
     "N_A": dict(_N, use_attention=True),
+    "GEM_N": dict(_N, use_attention=False, global_descriptor_method="gem"),
+    "GEM_S_A": dict(_S, use_attention=True, global_descriptor_method="gem"),
+    "CONVAP_S_A": dict(_S, use_attention=True, global_descriptor_method="convap"),
 }
 V3_CONFIGS = {
     "S": dict(_S, use_attention=False),
@@ -43,6 +46,7 @@ V3_CONFIGS = {
               encoder_dim=48, use_attention=False),
     "N_A": dict(nfeatures=32, channel_dims=[16, 24, 24, 48, 48, 96], downsample=2, leaky_relu=True,
                 encoder_dim=48, use_attention=True),
+    "CONVAP_S_A": dict(_S, use_attention=True, global_descriptor_method="convap"),
 }
 
 
@@ -52,6 +56,8 @@ def get_config(name: str, v3: bool = False) -> dict:
         raise ValueError(f"Config {name} not supported by the oracle, choose from {list(table)}")
     cfg = dict(table[name])
     cfg.setdefault("num_clusters", 64)  # kp2dtiny.py:308 / :690
+    cfg.setdefault("global_descriptor_method", "netvlad")
+    cfg.setdefault("remove_netvlad", False)
     cfg["v3"] = v3
     return cfg
 
@@ -144,8 +150,15 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
         s.update(_conv_shapes("seg_head.featB", ch // 2, nf))
     for i in (1, 2, 3):
         s.update(_cbr_shapes(f"vlad_head.convlad{i}", c4 if i == 1 else enc, enc))
-    s["vlad_head.netvlad.centroids"] = (K, enc)
-    s.update(_conv_shapes("vlad_head.netvlad.conv", enc, K, 1, bias=False))
+    method = cfg.get("global_descriptor_method", "netvlad")
+    if method == "netvlad":
+        if not cfg.get("remove_netvlad", False):
+            s["vlad_head.netvlad.centroids"] = (K, enc)
+            s.update(_conv_shapes("vlad_head.netvlad.conv", enc, K, 1, bias=False))
+    elif method == "gem":
+        s["vlad_head.netvlad.p"] = (1,)                                  # aggregators/gem.py:10
+    elif method == "convap":
+        s.update(_conv_shapes("vlad_head.netvlad.channel_pool", enc, enc, 1))   # aggregators/convap.py:23-25
     return s
 
 
@@ -438,7 +451,36 @@ def vpr_head(x, p, cfg, taps=None):
     v = cbr(v, p, "vlad_head.convlad3", lk)
     if taps is not None:
         taps["vlad_head.enc"] = v
+    method = cfg.get("global_descriptor_method", "netvlad")
+    if method == "gem":
+        return gem(v, p)
+    if method == "convap":
+        return convap(v, p)
+    if cfg.get("remove_netvlad", False):
+        return v                                    # vpr.py:84: the encoder map itself, NCHW
     return netvlad(v, p)
+
+
+def gem(x, p, prefix="vlad_head.netvlad", unshuffle=4, eps=1e-6):
+    """GeM.forward — modules/aggregators/gem.py:21-31: PixelUnshuffle(4), clamp(min=eps)^p, global mean, ^(1/p)."""
+    B, C, H, W = x.shape
+    r = unshuffle
+    x = x.reshape(B, C, H // r, r, W // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(B, C * r * r, H // r, W // r)
+    pw = p[f"{prefix}.p"].astype(x.dtype)[0]
+    return (np.maximum(x, x.dtype.type(eps)) ** pw).mean(axis=(2, 3)) ** (x.dtype.type(1) / pw)
+
+
+def convap(x, p, prefix="vlad_head.netvlad", s1=4, s2=4):
+    """ConvAP.forward — modules/aggregators/convap.py:28-34: 1x1 conv + bias, AdaptiveAvgPool2d((4,4)), L2."""
+    x = conv2d_1x1(x, p[f"{prefix}.channel_pool.weight"], p[f"{prefix}.channel_pool.bias"])
+    B, C, H, W = x.shape
+    out = np.zeros((B, C, s1, s2), x.dtype)
+    for a in range(s1):
+        y0, y1 = (a * H) // s1, -((-(a + 1) * H) // s1)
+        for b in range(s2):
+            x0, x1 = (b * W) // s2, -((-(b + 1) * W) // s2)
+            out[:, :, a, b] = x[:, :, y0:y1, x0:x1].mean(axis=(2, 3))
+    return l2_normalize(out.reshape(B, -1), axis=1)
 
 
 def sigmoid(x):
@@ -497,7 +539,19 @@ def grid_sample_bilinear(feat, gx, gy):
     return out
 
 
-def post_processing(out, H, W, cfg, training=False):
+def grid_sample_nearest(t, gx, gy):
+    """F.grid_sample(mode="nearest", align_corners=True, zeros) — kp2dtiny.py:635-637 (sample_segmentation)."""
+    B, C, Hi, Wi = t.shape
+    dt = t.dtype
+    ix = np.rint((gx + dt.type(1)) / dt.type(2) * dt.type(Wi - 1)).astype(np.int64)   # nearbyint: half to even
+    iy = np.rint((gy + dt.type(1)) / dt.type(2) * dt.type(Hi - 1)).astype(np.int64)
+    ok = (ix >= 0) & (ix < Wi) & (iy >= 0) & (iy < Hi)
+    bi = np.arange(B)[:, None, None]
+    val = t[bi, :, np.clip(iy, 0, Hi - 1), np.clip(ix, 0, Wi - 1)] * ok[..., None]
+    return val.transpose(0, 3, 1, 2)
+
+
+def post_processing(out, H, W, cfg, training=False, sample_segmentation=False):
     """KP2DTinyV2.post_processing (kp2dtiny.py:593-625) / V3 (:959-993).
 
     score * border mask (:520-528); coord = grid*cell + (cell-1)/2 + shift*cross_ratio*(cell-1)/2,
@@ -526,7 +580,10 @@ def post_processing(out, H, W, cfg, training=False):
         gy = coord[:, 1] / dt.type((H - 1) / 2.0) - dt.type(1)
         f = grid_sample_bilinear(feat, gx, gy)
         feat = f / np.sqrt((f * f).sum(axis=1, keepdims=True))
-        res["seg"] = out["seg"].argmax(axis=1)[:, None].astype(np.int64)
+        seg = out["seg"]
+        if sample_segmentation:
+            seg = grid_sample_nearest(seg, gx, gy)
+        res["seg"] = seg.argmax(axis=1)[:, None].astype(np.int64)
     res["feat"], res["coord"], res["score"] = feat, coord, score
     return res
 

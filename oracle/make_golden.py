@@ -44,6 +44,10 @@ CASES = {
     "v3_SA_240x320": ("S_A", True, 28, 240, 320, 1, 7, False, 4, False),    # demo.py config
     "v3_SA_480x640": ("S_A", True, 19, 480, 640, 1, 7, False, 8, False),    # BASELINE cfg 3 shape
     "v3_NA_120x160": ("N_A", True, 28, 120, 160, 1, 7, False, 2, False),
+    # config-selectable poolers; GeM's PixelUnshuffle(4) needs H/4, W/4 divisible by 4
+    "v2_GEM_SA_128x160": ("GEM_S_A", False, 28, 128, 160, 1, 8, False, 4, False),
+    "v2_GEM_N_64x96": ("GEM_N", False, 28, 64, 96, 2, 8, False, 2, False),
+    "v3_CONVAP_SA_120x160": ("CONVAP_S_A", True, 19, 120, 160, 1, 8, False, 4, False),
 }
 
 

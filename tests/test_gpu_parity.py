@@ -107,6 +107,31 @@ def test_against_oracle_other_shapes(config, v3, ncls, B, H, W):
     assert (post_np["seg"] != refp["seg"]).mean() < 2e-3
 
 
+def test_remove_netvlad_and_sample_segmentation():
+    """to_export configs return the encoder map as "vlad" (vpr.py:84); sample_segmentation=True samples the class map
+    at the keypoint coordinates with nearest-neighbour grid_sample (kp2dtiny.py:634-639)."""
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from oracle.weights import spread_state_dict
+    model = tiny_factory("S", 28, to_export=True)
+    sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    model.training = False
+    model.sample_segmentation = True
+    x = synthetic_frames(2, 48, 64, seed=6)
+    cfg = orc.get_config("S")
+    cfg["remove_netvlad"] = True
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(DEV))
+        ref = orc.forward(x, sd, cfg)
+        assert out["vlad"].shape == (2, 64, 12, 16)
+        assert np.max(np.abs(out["vlad"].cpu().numpy() - ref["vlad"])) < TOL
+        post = model.post_processing(out, 48, 64)
+    refp = orc.post_processing(ref, 48, 64, cfg, sample_segmentation=True)
+    assert post["seg"].shape == (2, 1, 12, 16) and post["seg"].dtype == torch.int64
+    assert (post["seg"].cpu().numpy() != refp["seg"]).mean() < 0.02      # cells whose coord rounds on a pixel boundary
+
+
 def test_training_mode_semantics():
     """model.training True: V3 returns logits (no Softmax2d) and post_processing skips sampling (kp2dtiny.py:615,942)."""
     model, sd = product_model("S", True, 19)

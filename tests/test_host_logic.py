@@ -79,14 +79,22 @@ def test_no_cpu_path():
 
 
 def test_unbuilt_variants_raise_not_fallback():
-    for kw in (dict(to_mcu=True), dict(to_export=True)):
-        m = K.tiny_factory("S", 28, **kw)
-        with pytest.raises(NotImplementedError):
-            m._check_built()
+    m = K.tiny_factory("S", 28, to_mcu=True)
     with pytest.raises(NotImplementedError):
-        K.KP2DTinyV2(**K.get_config("GEM_N"), nClasses=28)._check_built()
+        m._check_built()
     with pytest.raises(NotImplementedError):
         K.KP2DTinyV2(**K.get_config("S"), nClasses=28, depth=True)._check_built()
+
+
+@pytest.mark.parametrize("name,v3", [("GEM_S_A", False), ("GEM_N", False), ("CONVAP_S_A", False), ("CONVAP_S_A", True)])
+def test_pooler_variants_state_dict_layout(name, v3):
+    m = K.tiny_factory(name, 28, v3=v3)
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == list(orc.state_dict_shapes(orc.get_config(name, v3), 28).items())
+    assert m.global_desc_dim == m.encoder_dim * 16
+    m._check_built()
+    e = K.tiny_factory("S", 28, to_export=True)          # remove_netvlad: no pooler parameters at all
+    assert not any(k.startswith("vlad_head.netvlad") for k in e.state_dict()) and e.global_desc_dim == 0
 
 
 def test_shard_range_partitions_frames():

@@ -20,7 +20,7 @@ def test_forward_and_post_match_reference(name):
     out = orc.forward(x, sd, cfg)
     assert np.max(np.abs(out["score"] - z["fwd_score"])) < TOL
     assert np.max(np.abs(out["coord"] - z["fwd_shift"])) < TOL
-    assert np.max(np.abs(out["vlad"] - z["fwd_vlad"])) < 1e-6
+    assert np.max(np.abs(out["vlad"] - z["fwd_vlad"])) < 1e-5   # NetVLAD: ~2e-8; GeM (powf): ~3e-6
     assert np.max(np.abs(out["feat"][:, :, ::st, ::st] - z["fwd_feat"])) < TOL
     assert np.max(np.abs(out["seg"][:, :, ::st, ::st] - z["fwd_seg"])) < TOL
     post = orc.post_processing(out, meta["H"], meta["W"], cfg)
