@@ -57,6 +57,7 @@ typedef struct kp2d_config {
   int32_t device;           /* HIP device ordinal                                                        */
   int32_t global_descriptor;/* KP2D_GD_NETVLAD / KP2D_GD_GEM / KP2D_GD_CONVAP (vpr.py:53-76)                     */
   int32_t remove_netvlad;   /* to_export configs: "vlad" is the encoder map [B,enc,H/4,W/4] (vpr.py:84)          */
+  int32_t depth;            /* depth=True: V2 second seg-like head, V3 third slice + featD (kp2dtiny.py:402-437)  */
 } kp2d_config;
 #define KP2D_GD_NETVLAD 0
 #define KP2D_GD_GEM 1
@@ -96,8 +97,10 @@ size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W);
  *   feat   [B,nfeatures,H/2,W/2] dense descriptors   seg   [B,n_classes,H/2,W/2] logits (V3 eval: probabilities)
  *   vlad   [B,kp2d_vlad_dim]: NetVLAD K*C; GeM / ConvAP encoder_dim*16; remove_netvlad: [B,encoder_dim,H/4,W/4] */
 size_t kp2d_vlad_dim(const kp2d_model* m, int H, int W);
+/*   depth  [B,1,H/2,W/2] sigmoid, only for depth=1 models (NULL otherwise) */
 int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
-                 float* feat, float* seg, float* vlad, void* workspace, size_t workspace_bytes, void* stream);
+                 float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
+                 void* stream);
 
 /* replaces: post_processing (kp2dtiny.py:593-625 / :959-993).  `desc` and `seg_ids` may be NULL when the
  * module is in training mode (the reference skips sampling: kp2dtiny.py:615).

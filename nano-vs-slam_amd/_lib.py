@@ -35,6 +35,7 @@ class Kp2dConfig(C.Structure):
         ("device", C.c_int32),
         ("global_descriptor", C.c_int32),
         ("remove_netvlad", C.c_int32),
+        ("depth", C.c_int32),
     ]
 
 
@@ -59,7 +60,7 @@ SIGNATURES = {
     "kp2d_export_packed": (C.c_int, [_P, _P, _P]),
     "kp2d_import_packed": (C.c_int, [_P, _P, _P]),
     "kp2d_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
-    "kp2d_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kp2d_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kp2d_post": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 11 + [_P, _P, _P, _P, C.c_int, _P]),
     "kp2d_vlad_dim": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "kp2d_select_topk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),

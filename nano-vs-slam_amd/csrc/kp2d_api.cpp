@@ -253,28 +253,46 @@ int describe(kp2d_model* m) {
   }
   const int ch = c5, cexp = c4 + c3;
   const int last_in = v3 ? ch / 2 : ch;
-  if (g.use_attention) {
-    if (ch > 64 || (ch % 16)) return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 64, multiple of 16)", ch);
-    add_cbr(m, "seg_head.convs.0", c4, ch);
-    add_attention_module(m, "seg_head.convs.1", ch);
-    add_attention_module(m, "seg_head.convs.2", ch);
-    add_cbr(m, "seg_head.convs.3", ch, d1, true);
-    add_cbr(m, "seg_head.convs.4", ch + d1 / 4, ch);
-    add_cbr(m, "seg_head.convs.5", ch, d1, true);
-    add_cbr(m, "seg_head.convs.6", cexp, ch);
-    add_conv(m, "seg_head.convs.7", last_in, g.n_classes);
-  } else {
-    add_cbr(m, "seg_head.convs.0", c4, ch);
-    add_cbr(m, "seg_head.convs.1", ch, ch);
-    add_cbr(m, "seg_head.convs.2", ch, ch);
-    add_cbr(m, "seg_head.convs.3", ch, ch);
-    add_cbr(m, "seg_head.convs.4", ch, d1, true);
-    add_cbr(m, "seg_head.convs.5", ch + d1 / 4, ch);
-    add_cbr(m, "seg_head.convs.6", ch, d1, true);
-    add_cbr(m, "seg_head.convs.7", cexp, ch);
-    add_conv(m, "seg_head.convs.8", last_in, g.n_classes);
+  // V3 depth: the last CBR is half a width wider and a third 3x3 conv (featD, no bias) reads the middle slice
+  const int trunk_out = (v3 && g.depth) ? ch + ch / 2 : ch;
+  if (g.use_attention && (ch > 64 || (ch % 16)))
+    return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 64, multiple of 16)", ch);
+  auto seg_like_head = [&](const std::string& P_, int c_out, int width) {
+    const std::string L = P_ + ".convs.";
+    if (g.use_attention) {
+      add_cbr(m, L + "0", c4, ch);
+      add_attention_module(m, L + "1", ch);
+      add_attention_module(m, L + "2", ch);
+      add_cbr(m, L + "3", ch, d1, true);
+      add_cbr(m, L + "4", ch + d1 / 4, ch);
+      add_cbr(m, L + "5", ch, d1, true);
+      add_cbr(m, L + "6", cexp, width);
+      add_conv(m, L + "7", P_ == "seg_head" ? last_in : ch, c_out);
+    } else {
+      add_cbr(m, L + "0", c4, ch);
+      add_cbr(m, L + "1", ch, ch);
+      add_cbr(m, L + "2", ch, ch);
+      add_cbr(m, L + "3", ch, ch);
+      add_cbr(m, L + "4", ch, d1, true);
+      add_cbr(m, L + "5", ch + d1 / 4, ch);
+      add_cbr(m, L + "6", ch, d1, true);
+      add_cbr(m, L + "7", cexp, width);
+      add_conv(m, L + "8", P_ == "seg_head" ? last_in : ch, c_out);
+    }
+  };
+  seg_like_head("seg_head", g.n_classes, trunk_out);
+  if (v3) {
+    add_conv(m, "seg_head.featB", ch / 2, g.nfeatures);
+    if (g.depth) {   // Conv2d(dim_split, 1, bias=False): segmentation.py:281-284
+      add_spec(m, "seg_head.featD.weight", {1, ch / 2, 3, 3});
+      ConvPack c;
+      c.name = "seg_head.featD"; c.bn = false; c.bias = false; c.cin = ch / 2; c.cout = 1;
+      m->conv_index[c.name] = (int)m->convs.size();
+      m->convs.push_back(c);
+    }
+  } else if (g.depth) {
+    seg_like_head("depth_head", 1, ch);   // kp2dtiny.py:402-437: a second full segmentation head with one output
   }
-  if (v3) add_conv(m, "seg_head.featB", ch / 2, g.nfeatures);
   add_cbr(m, "vlad_head.convlad1", c4, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad2", g.encoder_dim, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad3", g.encoder_dim, g.encoder_dim);
@@ -650,7 +668,7 @@ struct Plan {
 
 struct FwdOut {
   const float* x;
-  float *score, *shift, *feat, *seg, *vlad;
+  float *score, *shift, *feat, *seg, *vlad, *depth;
 };
 
 // KP2DTinyV2.forward (kp2dtiny.py:552-591) / KP2DTinyV3.forward (:906-957) as a launch sequence
@@ -719,49 +737,63 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   }
 
   // ---- segmentation head: segmentation.py:126-157 (V2), :321-347 (V3), :442-466 (V2 att), :588-619 (V3 att) ----
-  {
+  // trunk(prefix) runs everything up to the last CBR(c_exp -> width) and returns it plus the name of the final conv
+  auto trunk = [&](const std::string& hp, std::string* last) -> Act {
+    const std::string L = hp + ".convs.";
     Act g5{};
-    int i;   // index of the CBR(c_exp -> c_hidden) layer
+    int i;   // index of the second-to-last shuffle CBR
     if (g.use_attention) {
-      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // feeds LayerNorm
-      Act a1 = P.attention_module("seg_head.convs.1", g0, /*pool=*/true, /*s16out=*/false);
+      Act g0 = P.cbr(L + "0", xb, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // feeds LayerNorm
+      Act a1 = P.attention_module(L + "1", g0, /*pool=*/true, /*s16out=*/false);
       P.release(g0);
-      Act a2 = P.attention_module("seg_head.convs.2", a1, false, /*s16out=*/true);          // feeds convs.3
+      Act a2 = P.attention_module(L + "2", a1, false, /*s16out=*/true);          // feeds convs.3
       P.release(a1);
-      Act g4 = P.cbr("seg_head.convs.3", a2, nullptr, ST_SHUFFLE);
+      Act g4 = P.cbr(L + "3", a2, nullptr, ST_SHUFFLE);
       P.release(a2);
-      g5 = P.cbr("seg_head.convs.4", g4, &xb, ST_NHWC);
+      g5 = P.cbr(L + "4", g4, &xb, ST_NHWC);
       P.release(g4);
       i = 5;
     } else {
-      Act g0 = P.cbr("seg_head.convs.0", xb, nullptr, ST_NHWC);
-      Act g1 = P.cbr("seg_head.convs.1", g0, nullptr, ST_NHWC_POOL);
+      Act g0 = P.cbr(L + "0", xb, nullptr, ST_NHWC);
+      Act g1 = P.cbr(L + "1", g0, nullptr, ST_NHWC_POOL);
       P.release(g0);
-      Act g2 = P.cbr("seg_head.convs.2", g1, nullptr, ST_NHWC);
+      Act g2 = P.cbr(L + "2", g1, nullptr, ST_NHWC);
       P.release(g1);
-      Act g3 = P.cbr("seg_head.convs.3", g2, nullptr, ST_NHWC);
+      Act g3 = P.cbr(L + "3", g2, nullptr, ST_NHWC);
       P.release(g2);
-      Act g4 = P.cbr("seg_head.convs.4", g3, nullptr, ST_SHUFFLE);
+      Act g4 = P.cbr(L + "4", g3, nullptr, ST_SHUFFLE);
       P.release(g3);
-      g5 = P.cbr("seg_head.convs.5", g4, &xb, ST_NHWC);
+      g5 = P.cbr(L + "5", g4, &xb, ST_NHWC);
       P.release(g4);
       i = 6;
     }
-    const std::string L = "seg_head.convs.";
     Act g6 = P.cbr(L + std::to_string(i), g5, nullptr, ST_SHUFFLE);
     P.release(g5);
     Act g7 = P.cbr(L + std::to_string(i + 1), g6, &skip, ST_NHWC);
     P.release(g6);
-    const std::string last = L + std::to_string(i + 2);
+    *last = L + std::to_string(i + 2);
+    return g7;
+  };
+  {
+    std::string last;
+    Act g7 = trunk("seg_head", &last);
     if (v3) {
-      const int half = g7.C / 2;   // dim_split = c_hidden // 2 (segmentation.py:190, :339-343)
+      const int half = m->c5 / 2;   // dim_split = c_hidden // 2 (segmentation.py:190, :339-343)
       P.conv("seg_head.featB", g7, half, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
+      if (g.depth)   // depth = featD(seg[:, half:2*half]).sigmoid()  (segmentation.py:340-341, kp2dtiny.py:956)
+        P.conv("seg_head.featD", g7, half, half, nullptr, ACT_SIGMOID, ST_NCHW, o.depth, 0, 0, nullptr, 0, 0, 1, H2, W2);
       const bool sm = (flags & KP2D_FWD_EVAL) && !g.remove_softmax;
       P.conv(last, g7, half, g7.C - half, nullptr, sm ? ACT_SOFTMAX_C : ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0,
              g.n_classes, H2, W2);
     } else {
       P.conv(last, g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
     }
+    P.release(g7);
+  }
+  if (!v3 && g.depth) {   // depth = depth_head(x, skip).sigmoid()  (kp2dtiny.py:588-590)
+    std::string last;
+    Act g7 = trunk("depth_head", &last);
+    P.conv(last, g7, g7.C, 0, nullptr, ACT_SIGMOID, ST_NCHW, o.depth, 0, 0, nullptr, 0, 0, 1, H2, W2);
     P.release(g7);
   }
 
@@ -999,8 +1031,10 @@ size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
 }
 
 int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
-                 float* feat, float* seg, float* vlad, void* workspace, size_t workspace_bytes, void* stream) {
+                 float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
+                 void* stream) {
   if (!m || !x || !score || !shift || !feat || !seg || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
+  if (m->cfg.depth && !depth) return fail(KP2D_ERR_ARG, "depth=1 model needs the depth output");
   if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised (kp2d_finalize_weights / kp2d_import_packed)");
   int rc = validate_shape(m, B, H, W);
   if (rc != KP2D_OK) return rc;
@@ -1044,6 +1078,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     o.feat = feat + (size_t)b0 * g.nfeatures * H2 * W2;
     o.seg = seg + (size_t)b0 * g.n_classes * H2 * W2;
     o.vlad = vlad + (size_t)b0 * kp2d_vlad_dim(m, H, W);
+    o.depth = depth ? depth + (size_t)b0 * H2 * W2 : nullptr;
     build(P, o, flags);
     if (P.rc != KP2D_OK) return P.rc;
   }

@@ -177,22 +177,25 @@ class _AttentionModule(_Holder):
 class _SegHead(_Holder):
     """Parameters of the four segmentation heads (reference modules/decoders/segmentation.py)."""
 
-    def __init__(self, c_in, c_hidden, c_exp, c_out, d1, mom, attention, n_feat=None):
+    def __init__(self, c_in, c_hidden, c_exp, c_out, d1, mom, attention, n_feat=None, depth=False):
         super().__init__()
         fused = n_feat is not None          # V3 "decoder fusion": feat + seg from one trunk
         last_in = c_hidden // 2 if fused else c_hidden
+        c_hidden_b = c_hidden + c_hidden // 2 if (fused and depth) else c_hidden   # segmentation.py:190-193
         if attention:
             layers = [_CBR(c_in, c_hidden, mom), _AttentionModule(c_hidden), _AttentionModule(c_hidden),
                       _CBR(c_hidden, d1, mom), _CBR(c_hidden + d1 // 4, c_hidden, mom), _CBR(c_hidden, d1, mom),
-                      _CBR(c_exp, c_hidden, mom), nn.Conv2d(last_in, c_out, 3, 1, 1)]
+                      _CBR(c_exp, c_hidden_b, mom), nn.Conv2d(last_in, c_out, 3, 1, 1)]
         else:
             layers = [_CBR(c_in, c_hidden, mom), _CBR(c_hidden, c_hidden, mom), _CBR(c_hidden, c_hidden, mom),
                       _CBR(c_hidden, c_hidden, mom), _CBR(c_hidden, d1, mom),
-                      _CBR(c_hidden + d1 // 4, c_hidden, mom), _CBR(c_hidden, d1, mom), _CBR(c_exp, c_hidden, mom),
+                      _CBR(c_hidden + d1 // 4, c_hidden, mom), _CBR(c_hidden, d1, mom), _CBR(c_exp, c_hidden_b, mom),
                       nn.Conv2d(last_in, c_out, 3, 1, 1)]
         self.convs = nn.ModuleList(layers)
         if fused:
             self.featB = nn.Conv2d(c_hidden // 2, n_feat, 3, 1, 1)
+            if depth:
+                self.featD = nn.Conv2d(c_hidden // 2, 1, 3, 1, 1, bias=False)
 
     def freeze(self, except_last_layer=False):
         for p in self.parameters():
@@ -320,14 +323,13 @@ class _KP2DTinyBase(nn.Module):
         cfg.device = device_index
         cfg.global_descriptor = _lib.GLOBAL_DESCRIPTORS[self.global_descriptor_method]
         cfg.remove_netvlad = int(bool(self.remove_netvlad))
+        cfg.depth = int(bool(self.depth))
         return cfg
 
     def _check_built(self):
         why = None
         if self.upscale_method != "pixelshuffle":
             why = f"upscale_method={self.upscale_method!r} (to_mcu path)"
-        elif self.depth:
-            why = "depth=True"
         if why:
             raise NotImplementedError(f"{why} is outside the path built so far (DESIGN.md, 'out of scope / next')")
 
@@ -414,12 +416,16 @@ class _KP2DTinyBase(nn.Module):
         vdim = eng.lib.kp2d_vlad_dim(eng.handle, H, W)
         vlad = (torch.empty(B, self.encoder_dim, Hc, Wc, device=dev) if self.remove_netvlad and
                 self.global_descriptor_method == "netvlad" else torch.empty(B, vdim, device=dev))
+        depth = torch.empty(B, 1, H2, W2, device=dev) if self.depth else None
         ws = eng.workspace(B, H, W, dev)
         flags = 0 if self.training else _lib.KP2D_FWD_EVAL
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(eng.lib.kp2d_forward(eng.handle, _ptr(x), B, H, W, flags, _ptr(score), _ptr(shift), _ptr(feat),
-                                        _ptr(seg), _ptr(vlad), _ptr(ws), ws.numel(), C.c_void_p(stream)))
-        return {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
+                                        _ptr(seg), _ptr(vlad), _ptr(depth), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
+        if self.depth:
+            out["depth"] = depth        # already sigmoid (kp2dtiny.py:588-590 / :955-956)
+        return out
 
     def post_processing(self, out, H, W):
         """Reference: post_processing kp2dtiny.py:593-625 / :959-993 (mutates and returns ``out``)."""
@@ -534,6 +540,8 @@ class KP2DTinyV2(_KP2DTinyBase):
         self.loc_head = _SimpleTaskHead(c4, c4, 2, mom)
         self.desc_head = _UpscaleHead(c4, c4, c3 * 4, c3 + c4, c4, nfeatures, mom)
         self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention)
+        if depth:
+            self.depth_head = _SegHead(c4, c5, c4 + c3, 1, d1, mom, use_attention)
         self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # reference force-sets this (kp2dtiny.py:456)
@@ -565,7 +573,7 @@ class KP2DTinyV3(_KP2DTinyBase):
         mom = bn_momentum
         self.backbone = _BackBone(3, c1, c2, c3, c4, 0.1)
         self.score_loc_head = _SimpleTaskHead(c4, c4, 3, mom)
-        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures)
+        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures, depth=depth)
         self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # kp2dtiny.py:813

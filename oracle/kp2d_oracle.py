@@ -58,6 +58,7 @@ def get_config(name: str, v3: bool = False) -> dict:
     cfg.setdefault("num_clusters", 64)  # kp2dtiny.py:308 / :690
     cfg.setdefault("global_descriptor_method", "netvlad")
     cfg.setdefault("remove_netvlad", False)
+    cfg.setdefault("depth", False)
     cfg["v3"] = v3
     return cfg
 
@@ -126,28 +127,40 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
         s.update(_conv_shapes("desc_head.confBb", c4, nf))
     # seg head: (c_in=c4, c_hidden=c5, c_exp=c4+c3, c_out=nClasses, d1)
     ch, cexp = c5, c4 + c3
-    last_in = ch // 2 if v3 else ch
-    if att:
-        s.update(_cbr_shapes("seg_head.convs.0", c4, ch))
-        s.update(_attmod_shapes("seg_head.convs.1", ch))
-        s.update(_attmod_shapes("seg_head.convs.2", ch))
-        s.update(_cbr_shapes("seg_head.convs.3", ch, d1))
-        s.update(_cbr_shapes("seg_head.convs.4", ch + d1 // 4, ch))
-        s.update(_cbr_shapes("seg_head.convs.5", ch, d1))
-        s.update(_cbr_shapes("seg_head.convs.6", cexp, ch))
-        s.update(_conv_shapes("seg_head.convs.7", last_in, n_classes))
-    else:
-        s.update(_cbr_shapes("seg_head.convs.0", c4, ch))
-        s.update(_cbr_shapes("seg_head.convs.1", ch, ch))
-        s.update(_cbr_shapes("seg_head.convs.2", ch, ch))
-        s.update(_cbr_shapes("seg_head.convs.3", ch, ch))
-        s.update(_cbr_shapes("seg_head.convs.4", ch, d1))
-        s.update(_cbr_shapes("seg_head.convs.5", ch + d1 // 4, ch))
-        s.update(_cbr_shapes("seg_head.convs.6", ch, d1))
-        s.update(_cbr_shapes("seg_head.convs.7", cexp, ch))
-        s.update(_conv_shapes("seg_head.convs.8", last_in, n_classes))
+    depth = cfg.get("depth", False)
+
+    def seg_like(prefix, c_out, width, last_in):
+        P = f"{prefix}.convs"
+        if att:
+            s.update(_cbr_shapes(f"{P}.0", c4, ch))
+            s.update(_attmod_shapes(f"{P}.1", ch))
+            s.update(_attmod_shapes(f"{P}.2", ch))
+            s.update(_cbr_shapes(f"{P}.3", ch, d1))
+            s.update(_cbr_shapes(f"{P}.4", ch + d1 // 4, ch))
+            s.update(_cbr_shapes(f"{P}.5", ch, d1))
+            s.update(_cbr_shapes(f"{P}.6", cexp, width))
+            s.update(_conv_shapes(f"{P}.7", last_in, c_out))
+        else:
+            s.update(_cbr_shapes(f"{P}.0", c4, ch))
+            s.update(_cbr_shapes(f"{P}.1", ch, ch))
+            s.update(_cbr_shapes(f"{P}.2", ch, ch))
+            s.update(_cbr_shapes(f"{P}.3", ch, ch))
+            s.update(_cbr_shapes(f"{P}.4", ch, d1))
+            s.update(_cbr_shapes(f"{P}.5", ch + d1 // 4, ch))
+            s.update(_cbr_shapes(f"{P}.6", ch, d1))
+            s.update(_cbr_shapes(f"{P}.7", cexp, width))
+            s.update(_conv_shapes(f"{P}.8", last_in, c_out))
+
     if v3:
+        # depth=True widens the last CBR by c_hidden//2 and adds featD (segmentation.py:190-193, 281-284)
+        seg_like("seg_head", n_classes, ch + ch // 2 if depth else ch, ch // 2)
         s.update(_conv_shapes("seg_head.featB", ch // 2, nf))
+        if depth:
+            s.update(_conv_shapes("seg_head.featD", ch // 2, 1, bias=False))
+    else:
+        seg_like("seg_head", n_classes, ch, ch)
+        if depth:
+            seg_like("depth_head", 1, ch, ch)            # kp2dtiny.py:402-437
     for i in (1, 2, 3):
         s.update(_cbr_shapes(f"vlad_head.convlad{i}", c4 if i == 1 else enc, enc))
     method = cfg.get("global_descriptor_method", "netvlad")
@@ -370,14 +383,14 @@ def attention_module(x, p, prefix, taps=None):
     return x
 
 
-def seg_trunk(x, skip, p, cfg, taps=None):
+def seg_trunk(x, skip, p, cfg, taps=None, head="seg_head"):
     """Shared trunk of the four segmentation heads up to the last CBR(c_exp -> c_hidden).
 
     no-att: modules/decoders/segmentation.py:126-152 (V2) / :321-338 (V3)
     att:    :442-463 (V2) / :588-609 (V3)
     """
     lk = cfg["leaky_relu"]
-    P = "seg_head.convs"
+    P = f"{head}.convs"
     if cfg["use_attention"]:
         seg = cbr(x, p, f"{P}.0", lk)
         seg = attention_module(seg, p, f"{P}.1", taps)
@@ -399,13 +412,13 @@ def seg_trunk(x, skip, p, cfg, taps=None):
     seg = np.concatenate([pixel_shuffle2(seg), skip], axis=1)
     seg = cbr(seg, p, f"{P}.{i + 2}", lk)
     if taps is not None:
-        taps["seg_head.trunk"] = seg
+        taps[f"{head}.trunk"] = seg
     return seg, f"{P}.{i + 3}"
 
 
-def seg_head_v2(x, skip, p, cfg, taps=None):
+def seg_head_v2(x, skip, p, cfg, taps=None, head="seg_head"):
     """SegmentationHead / SegmentationHeadATT — segmentation.py:153-157 / :464-466: logits."""
-    seg, last = seg_trunk(x, skip, p, cfg, taps)
+    seg, last = seg_trunk(x, skip, p, cfg, taps, head)
     return conv_b(seg, p, last)
 
 
@@ -418,6 +431,8 @@ def seg_feat_head_v3(x, skip, p, cfg, taps=None):
     split = cfg["channel_dims"][4] // 2
     feat = conv_b(seg[:, :split], p, "seg_head.featB")
     seg_out = conv_b(seg[:, -split:], p, last)
+    if cfg.get("depth", False):
+        return seg_out, feat, conv_b(seg[:, split:2 * split], p, "seg_head.featD")
     return seg_out, feat
 
 
@@ -501,7 +516,8 @@ def forward(x, p, cfg, taps=None, eval_mode=True):
     if cfg["v3"]:
         sl = simple_task_head(xb, p, "score_loc_head", lk)
         score, shift = sigmoid(sl[:, 0:1]), np.tanh(sl[:, 1:3])
-        seg, feat = seg_feat_head_v3(xb, skip, p, cfg, taps)
+        r3 = seg_feat_head_v3(xb, skip, p, cfg, taps)
+        seg, feat = r3[0], r3[1]
         if eval_mode:
             seg = softmax(seg, axis=1)
     else:
@@ -510,7 +526,10 @@ def forward(x, p, cfg, taps=None, eval_mode=True):
         feat = upscale_head(xb, skip, p, "desc_head", lk)
         seg = seg_head_v2(xb, skip, p, cfg, taps)
     vlad = vpr_head(xb, p, cfg, taps)
-    return {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
+    out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
+    if cfg.get("depth", False):   # kp2dtiny.py:588-590 (V2: second head) / :955-956 (V3: featD slice); both sigmoid
+        out["depth"] = sigmoid(r3[2]) if cfg["v3"] else sigmoid(seg_head_v2(xb, skip, p, cfg, taps, "depth_head"))
+    return out
 
 
 def grid_sample_bilinear(feat, gx, gy):

@@ -48,13 +48,21 @@ CASES = {
     "v2_GEM_SA_128x160": ("GEM_S_A", False, 28, 128, 160, 1, 8, False, 4, False),
     "v2_GEM_N_64x96": ("GEM_N", False, 28, 64, 96, 2, 8, False, 2, False),
     "v3_CONVAP_SA_120x160": ("CONVAP_S_A", True, 19, 120, 160, 1, 8, False, 4, False),
+    # depth=True variants (kp2dtiny.py:402-437, segmentation.py:190-193): config name + "+depth"
+    "v2_S_depth_64x96": ("S+depth", False, 28, 64, 96, 1, 8, False, 2, False),
+    "v3_SA_depth_64x96": ("S_A+depth", True, 19, 64, 96, 1, 8, False, 2, False),
 }
 
 
 def build_reference(config, v3, n_classes):
-    from src.kp2dtiny.models.kp2dtiny import tiny_factory
+    from src.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory
     with contextlib.redirect_stdout(io.StringIO()):
-        model = tiny_factory(config, n_classes, v3=v3)
+        if config.endswith("+depth"):
+            import copy
+            conf = copy.deepcopy(get_config(config[:-6], v3=v3))
+            model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**conf, nClasses=n_classes, depth=True)
+        else:
+            model = tiny_factory(config, n_classes, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = spread_state_dict(shapes)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
@@ -76,7 +84,8 @@ def gaps(score_flat, ks, thr=0.7):
 def run_case(name, out_dir):
     config, v3, ncls, H, W, B, seed, smooth, stride, want_taps = CASES[name]
     model, shapes, sd = build_reference(config, v3, ncls)
-    cfg = orc.get_config(config, v3)
+    cfg = orc.get_config(config.replace("+depth", ""), v3)
+    cfg["depth"] = config.endswith("+depth")
     # the oracle's own key/shape table must equal the reference's registration order
     mine = orc.state_dict_shapes(cfg, ncls)
     assert list(mine.items()) == [(k, tuple(s)) for k, s in shapes.items()], f"{name}: state-dict layout drift"
@@ -110,6 +119,8 @@ def run_case(name, out_dir):
     arrays["fwd_vlad"] = fwd_np["vlad"]
     arrays["fwd_feat"] = fwd_np["feat"][:, :, ::stride, ::stride]
     arrays["fwd_seg"] = fwd_np["seg"][:, :, ::stride, ::stride]
+    if "depth" in fwd_np:
+        arrays["fwd_depth"] = fwd_np["depth"]
     arrays["post_score"] = post_np["score"]
     arrays["post_coord"] = post_np["coord"]
     arrays["post_feat"] = post_np["feat"]
@@ -146,6 +157,8 @@ def run_case(name, out_dir):
     errs["post_feat"] = float(np.max(np.abs(o_p["feat"] - post_np["feat"])))
     errs["post_coord"] = float(np.max(np.abs(o_p["coord"] - post_np["coord"])))
     errs["seg_argmax_mismatch"] = int((o_p["seg"] != post_np["seg"]).sum())
+    if "depth" in fwd_np:
+        errs["depth"] = float(np.max(np.abs(o_f["depth"] - fwd_np["depth"])))
     meta["oracle_vs_reference_fp32"] = errs
     # fp64 oracle vs reference: sizes the tolerance any faithful fp32 implementation needs
     p64 = orc.cast_params(p32, np.float64)

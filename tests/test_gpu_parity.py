@@ -47,7 +47,9 @@ def test_against_reference_golden(name, precision):
     model.set_precision(precision)
     H, W, st = meta["H"], meta["W"], meta["dense_stride"]
     fwd, post, post_np = _run(model, x, H, W)
-    assert set(fwd) == {"score", "coord", "feat", "vlad", "seg"}
+    assert set(fwd) == {"score", "coord", "feat", "vlad", "seg"} | ({"depth"} if "fwd_depth" in z else set())
+    if "fwd_depth" in z:
+        assert np.max(np.abs(fwd["depth"] - z["fwd_depth"])) < TOL
     assert np.max(np.abs(fwd["score"] - z["fwd_score"])) < TOL
     assert np.max(np.abs(fwd["coord"] - z["fwd_shift"])) < TOL
     assert np.max(np.abs(fwd["vlad"] - z["fwd_vlad"])) < 1e-5

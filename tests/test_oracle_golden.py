@@ -23,6 +23,8 @@ def test_forward_and_post_match_reference(name):
     assert np.max(np.abs(out["vlad"] - z["fwd_vlad"])) < 1e-5   # NetVLAD: ~2e-8; GeM (powf): ~3e-6
     assert np.max(np.abs(out["feat"][:, :, ::st, ::st] - z["fwd_feat"])) < TOL
     assert np.max(np.abs(out["seg"][:, :, ::st, ::st] - z["fwd_seg"])) < TOL
+    if "fwd_depth" in z:
+        assert np.max(np.abs(out["depth"] - z["fwd_depth"])) < TOL
     post = orc.post_processing(out, meta["H"], meta["W"], cfg)
     assert np.max(np.abs(post["score"] - z["post_score"])) < TOL
     assert np.max(np.abs(post["coord"] - z["post_coord"])) < 2e-4
