@@ -82,8 +82,9 @@ def test_unbuilt_variants_raise_not_fallback():
     m = K.tiny_factory("S", 28, to_mcu=True)
     with pytest.raises(NotImplementedError):
         m._check_built()
-    with pytest.raises(NotImplementedError):
-        K.KP2DTinyV2(**K.get_config("S"), nClasses=28, depth=True)._check_built()
+    K.KP2DTinyV2(**K.get_config("S"), nClasses=28, depth=True)._check_built()      # depth heads are built
+    d = K.KP2DTinyV3(**K.get_config("S", v3=True), nClasses=19, depth=True)
+    assert d.seg_head.convs[7].conv.weight.shape[0] == 96 and d.seg_head.featD.bias is None
 
 
 @pytest.mark.parametrize("name,v3", [("GEM_S_A", False), ("GEM_N", False), ("CONVAP_S_A", False), ("CONVAP_S_A", True)])
