@@ -54,7 +54,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   const int wave = tid >> 6;
   const int i = lane & 31;
   const int h = lane >> 5;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give each
+  // XCD a contiguous run of tiles: neighbouring tiles (shared halo rows/columns) then hit the same L2.
   int bid = blockIdx.x;
+  if (!(a.dbg & 64)) {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any grid size
+  }
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
