@@ -274,6 +274,8 @@ template <int CO>
 __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
   __shared__ __attribute__((aligned(16))) float s_w[27 * CO];
   __shared__ float s_sc[CO], s_sh[CO];
+  __shared__ __attribute__((aligned(16))) float4 s_o[256 * 4];
+  static_assert(CO == 16, "conv1a: the output staging assumes 16 channels (4 float4 per pixel)");
   for (int t = threadIdx.x; t < 27 * CO; t += 256) s_w[t] = a.w[t];
   for (int t = threadIdx.x; t < CO; t += 256) { s_sc[t] = a.scale[t]; s_sh[t] = a.shift[t]; }
   __syncthreads();
@@ -315,30 +317,41 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
         acc[c + 3] = fmaf(vk, w4.w, acc[c + 3]);
       }
     }
-    float4* dst = reinterpret_cast<float4*>(a.out + p * CO);
+    // BatchNorm affine + LeakyReLU / ReLU / identity as max(v, v*slope)
+    const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float t = fmaf(acc[c], s_sc[c], s_sh[c]);
+      acc[c] = fmaxf(t, t * slope);
+    }
     if (a.out_s16) {
-      // CO == 16: one S16 block = [16 hi halves][16 lo halves]
+      // CO == 16: one S16 block = [16 hi halves][16 lo halves] (conv_common.h)
       f16x8 hv[2], lv[2];
 #pragma unroll
       for (int c = 0; c < CO; ++c) {
-        const float v = act_apply(acc[c] * s_sc[c] + s_sh[c], a.act, c);
-        const _Float16 hi = (_Float16)v;
+        const _Float16 hi = (_Float16)acc[c];
         hv[c >> 3][c & 7] = hi;
-        lv[c >> 3][c & 7] = (_Float16)(v - (float)hi);
+        lv[c >> 3][c & 7] = (_Float16)(acc[c] - (float)hi);
       }
-      f16x8* d16 = reinterpret_cast<f16x8*>(dst);
-      d16[0] = hv[0]; d16[1] = hv[1]; d16[2] = lv[0]; d16[3] = lv[1];
-      return;
-    }
+      s_o[threadIdx.x * 4 + 0] = __builtin_bit_cast(float4, hv[0]);
+      s_o[threadIdx.x * 4 + 1] = __builtin_bit_cast(float4, hv[1]);
+      s_o[threadIdx.x * 4 + 2] = __builtin_bit_cast(float4, lv[0]);
+      s_o[threadIdx.x * 4 + 3] = __builtin_bit_cast(float4, lv[1]);
+    } else {
 #pragma unroll
-    for (int c = 0; c < CO; c += 4) {
-      float4 o;
-      o.x = act_apply(acc[c] * s_sc[c] + s_sh[c], a.act, c);
-      o.y = act_apply(acc[c + 1] * s_sc[c + 1] + s_sh[c + 1], a.act, c + 1);
-      o.z = act_apply(acc[c + 2] * s_sc[c + 2] + s_sh[c + 2], a.act, c + 2);
-      o.w = act_apply(acc[c + 3] * s_sc[c + 3] + s_sh[c + 3], a.act, c + 3);
-      dst[c / 4] = o;
+      for (int c = 0; c < CO; c += 4) s_o[threadIdx.x * 4 + c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
     }
+  }
+  // The 256 pixels of this workgroup are one contiguous 16 KiB run of the NHWC output: go through LDS so every
+  // store instruction of a wave writes 1 KiB of consecutive bytes (per-thread 64-byte rows cost 1.6x the write
+  // traffic: PMC WRITE_SIZE 505 MB vs 315 MB per launch, profiles/r1_traffic.json).
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 256;
+  float4* dst = reinterpret_cast<float4*>(a.out + base * CO);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = j * 256 + threadIdx.x;          // float4 index inside the block's run
+    if (base + (e >> 2) < npix) dst[e] = s_o[e];
   }
 }
 
