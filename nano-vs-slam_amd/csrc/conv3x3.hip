@@ -97,20 +97,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   constexpr int W_IT = (W_G + 255) / 256;
   float4 rin[IN_IT], rw[W_IT];
 
+  // Per-thread staging granules, computed ONCE: granule g = tid + 256*it is quad q = tid % Q of halo pixel
+  // p = g / Q.  Recomputing the divisions by 18 and the 64-bit addresses for every chunk cost ~600 VALU
+  // instructions per chunk per thread (KP2D_DBG=15 "skeleton" runs: 1.0 ms of a 4.2 ms forward).
+  const int st_q4 = 4 * (tid % Q);
+  int st_off0[IN_IT], st_off1[IN_IT], st_lds[IN_IT];
+  unsigned st_ok = 0;
+#pragma unroll
+  for (int it = 0; it < IN_IT; ++it) {
+    const int g = tid + 256 * it;
+    const int p = g / Q;
+    const int py = p / IN_ROWS, px = p - py * IN_ROWS;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W) st_ok |= 1u << it;
+    st_off0[it] = (int)(gy * a.in0.rs + gx * a.in0.ps) + st_q4;
+    st_off1[it] = (int)(gy * a.in1.rs + gx * a.in1.ps) + st_q4;
+    st_lds[it] = (py * IN_PITCH + px) * KCP;
+  }
+  const int w_lds = (tid / Q) * KCP + 4 * (tid % Q);     // weight granule it lands at w_lds + it * (256 / Q) * KCP
+
   auto prefetch = [&](int ch) {
+    const int c = ch * KC + st_q4;
+    const bool first = c < c0;
+    const float* src = first ? src0 + ch * KC : src1 + (ch * KC - c0);
+    const bool cok = c < a.cin && !(a.dbg & 4);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const int g = tid + 256 * it;
-      const int p = g / Q, q = g - p * Q;
-      const int py = p / IN_ROWS, px = p - py * IN_ROWS;
-      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-      const int c = ch * KC + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W && c < a.cin && !(a.dbg & 4)) {
-        const float* src = (c < c0) ? src0 + gy * a.in0.rs + gx * a.in0.ps + c
-                                    : src1 + gy * a.in1.rs + gx * a.in1.ps + (c - c0);
-        v = *reinterpret_cast<const float4*>(src);
-      }
+      if (cok && ((st_ok >> it) & 1)) v = *reinterpret_cast<const float4*>(src + (first ? st_off0[it] : st_off1[it]));
       rin[it] = v;
     }
     const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
@@ -124,15 +138,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const int g = tid + 256 * it;
-      if (IN_G % 256 != 0 && g >= IN_G) continue;
-      const int p = g / Q, q = g - p * Q;
-      const int py = p / IN_ROWS, px = p - py * IN_ROWS;
+      if (IN_G % 256 != 0 && tid + 256 * it >= IN_G) continue;
       const float4 v = rin[it];
       if (PREC == 0 || a.in_s16) {
         // fp32 operands, or a producer that already wrote [16 hi | 16 lo] fp16 blocks (conv_common.h):
         // the 64-byte block IS the LDS row
-        *reinterpret_cast<float4*>(&s_in[(py * IN_PITCH + px) * KCP + 4 * q]) = v;
+        *reinterpret_cast<float4*>(&s_in[st_lds[it] + st_q4]) = v;
       } else {
         // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; |x| is clamped to the fp16 range
         const float lim = 65000.f;
@@ -142,17 +153,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
         hi[0] = (_Float16)x0_; hi[1] = (_Float16)x1_; hi[2] = (_Float16)x2_; hi[3] = (_Float16)x3_;
         lo[0] = (_Float16)(x0_ - (float)hi[0]); lo[1] = (_Float16)(x1_ - (float)hi[1]);
         lo[2] = (_Float16)(x2_ - (float)hi[2]); lo[3] = (_Float16)(x3_ - (float)hi[3]);
-        _Float16* row = reinterpret_cast<_Float16*>(&s_in[(py * IN_PITCH + px) * KCP]);
-        *reinterpret_cast<f16x4*>(row + 4 * q) = hi;
-        *reinterpret_cast<f16x4*>(row + 16 + 4 * q) = lo;
+        _Float16* row = reinterpret_cast<_Float16*>(&s_in[st_lds[it]]);
+        *reinterpret_cast<f16x4*>(row + st_q4) = hi;
+        *reinterpret_cast<f16x4*>(row + 16 + st_q4) = lo;
       }
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-      const int g = tid + 256 * it;
-      if (W_G % 256 != 0 && g >= W_G) continue;
-      const int row = g / Q, q = g - row * Q;
-      *reinterpret_cast<float4*>(&s_w[row * KCP + 4 * q]) = rw[it];
+      if (W_G % 256 != 0 && tid + 256 * it >= W_G) continue;
+      *reinterpret_cast<float4*>(&s_w[w_lds + it * ((256 / Q) * KCP)]) = rw[it];
     }
   };
 
