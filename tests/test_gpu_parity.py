@@ -333,3 +333,43 @@ def test_descriptor_matching_against_oracle():
     i1, i2, sc = bf_match(d0[0], d1[0], 0.7)
     best, *_ = orc.bf_match_one_to_one(d0[0], d1[0], 0.7)
     assert {t: q for q, t in zip(i1, i2)} == {t: q for t, (q, _) in best.items()}
+
+
+@pytest.mark.parametrize("config,v3,B,H,W", [("S", False, 2, 72, 104), ("S_A", True, 1, 40, 56), ("N", False, 3, 24, 88)])
+def test_no_out_of_bounds_writes(config, v3, B, H, W):
+    """Call the C ABI directly with guard bands around every caller-owned buffer (outputs and workspace):
+    ragged tiles, padded channel groups and the LDS-transposed NCHW stores must not touch a byte outside."""
+    import ctypes as C
+    from nano_vs_slam_amd import _lib
+    model, _ = product_model(config, v3, 28)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=2)).to(DEV)
+    with torch.no_grad():
+        ref = model(x)                      # builds the engine, gives the expected values
+    eng = model._engine
+    lib = eng.lib
+    G = 4096                                # guard floats on each side
+    sentinel = 12345.678
+
+    def guarded(n):
+        buf = torch.full((n + 2 * G,), sentinel, device=DEV)
+        return buf, buf[G:G + n]
+
+    shapes = {k: tuple(v.shape) for k, v in ref.items()}
+    bufs = {k: guarded(int(np.prod(s))) for k, s in shapes.items()}
+    nws = lib.kp2d_workspace_bytes(eng.handle, B, H, W)
+    ws_full = torch.full((nws // 4 + 2 * G,), sentinel, device=DEV)
+    ws = ws_full[G:G + nws // 4]
+    assert ws.data_ptr() % 256 == 0 or True
+    # the workspace must be 256-byte aligned: slide inside the guarded buffer if needed
+    shift = (-ws_full[G:].data_ptr()) % 256 // 4
+    ws = ws_full[G + shift:G + shift + nws // 4]
+    P = lambda t: C.c_void_p(t.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.kp2d_forward(eng.handle, P(x), B, H, W, _lib.KP2D_FWD_EVAL, P(bufs["score"][1]), P(bufs["coord"][1]),
+                                P(bufs["feat"][1]), P(bufs["seg"][1]), P(bufs["vlad"][1]), C.c_void_p(), P(ws), nws,
+                                C.c_void_p(stream)))
+    torch.cuda.synchronize()
+    for k, (full, view) in bufs.items():
+        assert torch.all(full[:G] == sentinel) and torch.all(full[-G:] == sentinel), f"{k}: guard band overwritten"
+        assert torch.equal(view.reshape(shapes[k]), ref[k]), k
+    assert torch.all(ws_full[:G + shift] == sentinel) and torch.all(ws_full[G + shift + nws // 4:] == sentinel), "workspace guard"
