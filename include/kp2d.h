@@ -122,6 +122,11 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
 int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
                           float* pts, float* dsel, void* stream);
 
+/* replaces the per-frame front-end of inference() (src/evaluation/visual_odometry.py:77-87): kornia.image_to_tensor
+ * / 255, kornia bilinear resize (align_corners=False), .sub(0.5).mul(2).  frames: uint8 [B,Hs,Ws,3] on the device;
+ * x: float32 [B,3,H,W]. */
+int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int H, int W, void* stream);
+
 /* replaces: BfFeatureMatcher.match = cv2.BFMatcher(NORM_L2).knnMatch(k=2) + goodMatchesOneToOne
  * (src/visual_odometry/feature_matcher.py:89-98, :179-209), batched over B frame pairs, on device.
  *   d0 [B,max0,C] query descriptors, n0 [B] valid rows; d1 [B,max1,C] train descriptors, n1 [B]; C in {32,64}

@@ -1135,6 +1135,13 @@ int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* 
   return KP2D_OK;
 }
 
+int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int H, int W, void* stream) {
+  if (!frames || !x || B < 1 || Hs < 1 || Ws < 1 || H < 1 || W < 1) return fail(KP2D_ERR_ARG, "bad preprocess arguments");
+  int e = launch_preprocess(frames, x, B, Hs, Ws, H, W, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "preprocess kernel: %d", e);
+  return KP2D_OK;
+}
+
 int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
                            int max1, int C, float ratio, int32_t* nn_idx, float* nn_dist, float* nn_dist2,
                            int32_t* match_q, float* match_d, void* scratch, void* stream) {

@@ -262,6 +262,41 @@ int launch_gather(const GatherArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// Frame front-end (src/evaluation/visual_odometry.py:77-87): uint8 HWC frame -> /255 -> bilinear resize
+// (kornia.geometry.transform.resize = F.interpolate(bilinear, align_corners=False, no antialias)) -> (v - 0.5) * 2,
+// written as the planar [B,3,H,W] tensor the network reads.  One pass, no intermediate float image.
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* src, float* dst, int Hs, int Ws, int H, int W) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const unsigned char* img = src + (size_t)b * Hs * Ws * 3;
+  float v[3];
+  if (Hs == H && Ws == W) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (float)img[((size_t)y * Ws + x) * 3 + c] / 255.0f;
+  } else {
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)Hs / (float)H) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)Ws / (float)W) - 0.5f, 0.f);
+    const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
+    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+    const float wy = sy - (float)y0, wx = sx - (float)x0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a00 = (float)img[((size_t)y0 * Ws + x0) * 3 + c] / 255.0f, a01 = (float)img[((size_t)y0 * Ws + x1) * 3 + c] / 255.0f;
+      const float a10 = (float)img[((size_t)y1 * Ws + x0) * 3 + c] / 255.0f, a11 = (float)img[((size_t)y1 * Ws + x1) * 3 + c] / 255.0f;
+      v[c] = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[((size_t)b * 3 + c) * H * W + p] = (v[c] - 0.5f) * 2.0f;
+}
+
+int launch_preprocess(const unsigned char* src, float* dst, int B, int Hs, int Ws, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(preprocess_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, s, src, dst, Hs, Ws, H, W);
+  return (int)hipGetLastError();
+}
+
 // NHWC (with channel stride / offset) -> planar NCHW; used for API-facing copies of internal tensors.
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, float* out, int C, int HW, int istride,
                                                            int ioff) {

@@ -373,3 +373,23 @@ def test_no_out_of_bounds_writes(config, v3, B, H, W):
         assert torch.all(full[:G] == sentinel) and torch.all(full[-G:] == sentinel), f"{k}: guard band overwritten"
         assert torch.equal(view.reshape(shapes[k]), ref[k]), k
     assert torch.all(ws_full[:G + shift] == sentinel) and torch.all(ws_full[G + shift + nws // 4:] == sentinel), "workspace guard"
+
+
+def test_preprocess_front_end_matches_torch():
+    """kp2d_preprocess == /255 -> F.interpolate(bilinear, align_corners=False) -> (v - 0.5) * 2 (kornia's resize)."""
+    import torch.nn.functional as F
+    from nano_vs_slam_amd.pipeline import frames_to_input, inference
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (2, 150, 200, 3), dtype=np.uint8)
+    same = frames_to_input(frames, DEV).cpu()
+    ref_same = (torch.from_numpy(frames).permute(0, 3, 1, 2).float() / 255.0 - 0.5) * 2.0
+    assert torch.equal(same, ref_same)
+    for size in ((96, 128), (240, 320), (152, 200)):
+        got = frames_to_input(frames, DEV, size).cpu()
+        ref = (F.interpolate(torch.from_numpy(frames).permute(0, 3, 1, 2).float() / 255.0, size=size, mode="bilinear",
+                             align_corners=False) - 0.5) * 2.0
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6
+    model, _ = product_model("S", False, 28)
+    pts, feat, out = inference(model, frames[0], (96, 128), nn_thresh=0.3, top_k=100)
+    assert out["score"].shape == (1, 1, 24, 32) and pts.shape[1] == 2 and feat.shape[1] == 32
+    assert pts[:, 0].max() <= 200 and pts[:, 1].max() <= 150 and (len(pts) == 0 or pts[:, 0].max() > 128 * 0.9)
