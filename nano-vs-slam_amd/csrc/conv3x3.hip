@@ -240,6 +240,8 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + TAPS * NT * 32 * KCP) * sizeof(float);
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
+  const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float);   // [pixel][N] staging of the fp32 NHWC epilogue
+  if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC>),

@@ -141,6 +141,8 @@ static int launch_s16_t(const ConvArgs& a, hipStream_t s) {
   size_t lds = 2 * S_IN_BYTES + 2 * 3 * NT * 32 * 64;
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
+  const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float);   // [pixel][N] staging of the fp32 NHWC epilogue
+  if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s16_kernel<NT>),
