@@ -14,33 +14,52 @@ namespace kp2d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// one wave per pixel, lane = channel (C <= 64): the channel reduction is a 6-step wavefront butterfly
+// one wave per pixel, lane = channels lane, lane+64, ... (C <= 64*NV): the channel reduction is a 6-step butterfly
+template <int NV>
 __global__ __launch_bounds__(256) void channel_layernorm_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwave = (long)gridDim.x * 4;
   const int C = a.C;
-  const bool on = lane < C;
-  const float g = on ? a.g[lane] : 0.f, bb = on ? a.b[lane] : 0.f;
+  float g[NV], bb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bool on = lane + 64 * i < C;
+    g[i] = on ? a.g[lane + 64 * i] : 0.f;
+    bb[i] = on ? a.b[lane + 64 * i] : 0.f;
+  }
   const float invC = 1.f / (float)C;
   for (long p = wave; p < a.npix; p += nwave) {
-    const float v = on ? a.x[p * C + lane] : 0.f;
-    float s = v;
+    float v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = lane + 64 * i < C ? a.x[p * C + lane + 64 * i] : 0.f;
+      s += v[i];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s * invC;
-    const float d = on ? v - mean : 0.f;
-    float q = d * d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = lane + 64 * i < C ? v[i] - mean : 0.f;
+      q += v[i] * v[i];
+    }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float stdv = sqrtf(q * invC);          // torch.var(unbiased=False).sqrt()
-    if (on) a.y[p * C + lane] = d / (stdv + 1e-5f) * g + bb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < C) a.y[p * C + lane + 64 * i] = v[i] / (stdv + 1e-5f) * g[i] + bb[i];
   }
 }
 
 int launch_channel_layernorm(const LnArgs& a, hipStream_t s) {
-  if (a.C > 64 || a.C < 1) return -1400;
+  if (a.C > 256 || a.C < 1) return -1400;
   long blocks = (a.npix + 3) / 4;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(channel_layernorm_kernel, dim3((int)blocks), dim3(256), 0, s, a);
+  if (a.C <= 64) hipLaunchKernelGGL(channel_layernorm_kernel<1>, dim3((int)blocks), dim3(256), 0, s, a);
+  else if (a.C <= 128) hipLaunchKernelGGL(channel_layernorm_kernel<2>, dim3((int)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(channel_layernorm_kernel<4>, dim3((int)blocks), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -82,7 +101,7 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Streaming attention, exact fp32 on v_mfma_f32_16x16x4_f32.
-//   grid (ceil(S/64), heads, B); 4 waves, each owns 16 queries.  Head dim d <= 16 (padded to 16).
+//   grid (ceil(S/64), heads, B); 4 waves, each owns 16 queries.  Head dim d <= 64 (padded to 16-channel blocks).
 //   S^T tile = K_tile (16 keys x d) . Q^T (d x 16 queries): D[row = key 4g+reg][col = query lane&15], so a
 //   lane holds 4 keys of ONE query -> the softmax row reduction is 4 registers + two cross-lane steps.
 //   P^T in that same register layout is directly the B operand of O^T += V^T . P^T when the key order of
@@ -91,9 +110,12 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t s) {
 //   works as long as both operands use the same one.)
 // ---------------------------------------------------------------------------------------------
 constexpr int AKT = 64;   // keys per LDS chunk
-constexpr int ADP = 20;   // padded row (floats): 16-byte aligned, conflict-light for b128/b32 reads
 
+// DB = 16-channel blocks of the head dimension (d <= 16*DB, zero-padded): 1 for the S/N widths, 4 for LARGE_D (d = 64)
+template <int DB>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+  constexpr int ADP = 16 * DB + 4;   // padded row (floats): 16-byte aligned, conflict-light for b128/b32 reads
+  constexpr int DQ = 4 * DB;         // float4 per padded row
   __shared__ __attribute__((aligned(16))) float Ks[AKT * ADP];
   __shared__ __attribute__((aligned(16))) float Vs[AKT * ADP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,18 +125,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qi = q0 + j;
   const float* qp = a.q + ((size_t)b * S + (qi < S ? qi : 0)) * C + h * d;
-  float qf[4];
+  float qf[DB][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) qf[r] = (qi < S && 4 * g + r < d) ? qp[4 * g + r] : 0.f;
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * db + 4 * g + r;
+      qf[db][r] = (qi < S && c < d) ? qp[c] : 0.f;
+    }
 
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  f32x4 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
   const float* kvb = a.kv + (size_t)b * T * 2 * C + h * d;
-  const int skey = tid >> 2, squad = tid & 3;
 
   for (int kc = 0; kc < T; kc += AKT) {
     __syncthreads();
-    {
+    for (int e = tid; e < AKT * DQ; e += 256) {
+      const int skey = e / DQ, squad = e % DQ;
       float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
       const int key = kc + skey;
       if (key < T && 4 * squad < d) {
@@ -129,12 +158,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     f32x4 sc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float4 kf = *reinterpret_cast<const float4*>(&Ks[(16 * t + j) * ADP + 4 * g]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[3], acc, 0, 0, 0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(16 * t + j) * ADP + 16 * db + 4 * g]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[db][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[db][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[db][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[db][3], acc, 0, 0, 0);
+      }
       sc[t] = acc;
     }
     float mx = m;
@@ -151,7 +183,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float alpha = expf(m - mx);       // first chunk: exp(-inf) = 0
     l *= alpha;
-    o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
     m = mx;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -159,7 +192,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const float p = expf(sc[t][r] - mx);
         l += p;
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(16 * t + 4 * g + r) * ADP + j], p, o, 0, 0, 0);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(16 * t + 4 * g + r) * ADP + 16 * db + j], p, o[db], 0, 0, 0);
       }
   }
   l += __shfl_xor(l, 16);
@@ -168,15 +203,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const float inv = 1.f / l;
     float* op = a.out + ((size_t)b * S + qi) * C + h * d;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * g + r < d) op[4 * g + r] = o[r] * inv;
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * db + 4 * g + r < d) op[16 * db + 4 * g + r] = o[db][r] * inv;
   }
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t s) {
   const int d = a.C / a.heads;
-  if (a.C % a.heads || d > 16 || (d & 3) || (a.C & 3)) return -1402;
-  hipLaunchKernelGGL(attention_kernel, dim3((a.S + 63) / 64, a.heads, a.B), dim3(256), 0, s, a);
+  if (a.C % a.heads || d > 64 || (d & 3) || (a.C & 3)) return -1402;
+  const dim3 grid((a.S + 63) / 64, a.heads, a.B);
+  if (d <= 16) hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, a);
+  else if (d <= 32) hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

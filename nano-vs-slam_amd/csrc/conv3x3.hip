@@ -251,7 +251,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   }
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
-  if (a.store == ST_NCHW && groups != 1) return -1002;  // planar outputs are <= 64 channels
+  if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
   hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS, PREC>), dim3(grid, groups), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
@@ -366,10 +366,76 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
   }
 }
 
+// Any other first-layer width (LARGE_D: 64): same one-pixel-per-thread scheme, 16 output channels at a time,
+// each thread writing its own 64-byte rows.  Not tuned: only the 16-wide layer is on a measured path.
+__global__ __launch_bounds__(256) void conv1a_wide_kernel(const Conv1aArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int CO = a.cout;
+  float* s_w = s_dyn;                 // [27][CO]
+  float* s_sc = s_dyn + 27 * CO;      // [CO]
+  float* s_sh = s_sc + CO;            // [CO]
+  for (int t = threadIdx.x; t < 27 * CO; t += 256) s_w[t] = a.w[t];
+  for (int t = threadIdx.x; t < CO; t += 256) { s_sc[t] = a.scale[t]; s_sh[t] = a.shift[t]; }
+  __syncthreads();
+  const int H = a.H, W = a.W;
+  const size_t npix = (size_t)a.B * H * W;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  const int b = (int)(p / ((size_t)W * H));
+  float v[27];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci) {
+    const float* plane = a.x + ((size_t)b * 3 + ci) * H * W;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        v[ci * 9 + dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? plane[(size_t)yy * W + xx] : 0.f;
+      }
+    }
+  }
+  const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
+  for (int c0 = 0; c0 < CO; c0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll 3
+    for (int k = 0; k < 27; ++k) {
+      const float4* wr = reinterpret_cast<const float4*>(&s_w[k * CO + c0]);
+      const float vk = v[k];
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) {
+        const float4 w4 = wr[c / 4];
+        acc[c] = fmaf(vk, w4.x, acc[c]);
+        acc[c + 1] = fmaf(vk, w4.y, acc[c + 1]);
+        acc[c + 2] = fmaf(vk, w4.z, acc[c + 2]);
+        acc[c + 3] = fmaf(vk, w4.w, acc[c + 3]);
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + p * CO + c0);
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+      float r[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = fmaf(acc[c + i], s_sc[c0 + c + i], s_sh[c0 + c + i]);
+        r[i] = fmaxf(t, t * slope);
+      }
+      dst[c / 4] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
   const size_t npix = (size_t)a.B * a.H * a.W;
   const int grid = (int)((npix + 255) / 256);
   if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cout % 16 == 0 && a.cout <= 256 && !a.out_s16)
+    hipLaunchKernelGGL(conv1a_wide_kernel, dim3(grid), dim3(256), (size_t)29 * a.cout * sizeof(float), s, a);
   else return -1001;
   return (int)hipGetLastError();
 }

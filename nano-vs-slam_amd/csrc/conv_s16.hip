@@ -152,7 +152,7 @@ static int launch_s16_t(const ConvArgs& a, hipStream_t s) {
   }
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
-  if (a.store == ST_NCHW && groups != 1) return -1002;
+  if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;
   hipLaunchKernelGGL((conv3x3_s16_kernel<NT>), dim3(grid, groups), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }

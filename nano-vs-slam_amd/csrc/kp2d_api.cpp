@@ -255,8 +255,8 @@ int describe(kp2d_model* m) {
   const int last_in = v3 ? ch / 2 : ch;
   // V3 depth: the last CBR is half a width wider and a third 3x3 conv (featD, no bias) reads the middle slice
   const int trunk_out = (v3 && g.depth) ? ch + ch / 2 : ch;
-  if (g.use_attention && (ch > 64 || (ch % 16)))
-    return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 64, multiple of 16)", ch);
+  if (g.use_attention && (ch > 256 || (ch % 16)))
+    return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 256, multiple of 16)", ch);
   auto seg_like_head = [&](const std::string& P_, int c_out, int width) {
     const std::string L = P_ + ".convs.";
     if (g.use_attention) {
@@ -849,8 +849,9 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
 
 int validate_shape(const kp2d_model* m, int B, int H, int W) {
   if (B < 1) return fail(KP2D_ERR_ARG, "B must be >= 1");
-  if (H < 16 || W < 16 || (H % 8) || (W % 8)) return fail(KP2D_ERR_ARG, "H and W must be multiples of 8 and >= 16 (got %dx%d)", H, W);
-  if (m->cfg.downsample != 2) return fail(KP2D_ERR_UNSUPPORTED, "downsample=%d (only 2 is built)", m->cfg.downsample);
+  // the segmentation head pools the cell grid once more (segmentation.py:134): H, W divisible by 2 * cell
+  const int q = 2 << m->cfg.downsample;
+  if (H < 16 || W < 16 || (H % q) || (W % q)) return fail(KP2D_ERR_ARG, "H and W must be multiples of %d and >= 16 (got %dx%d)", q, H, W);
   return KP2D_OK;
 }
 
@@ -910,8 +911,9 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   m->cfg = *cfg;
   m->c1 = cfg->channel_dims[0]; m->c2 = cfg->channel_dims[1]; m->c3 = cfg->channel_dims[2];
   m->c4 = cfg->channel_dims[3]; m->c5 = cfg->channel_dims[4]; m->d1 = cfg->channel_dims[5];
-  if (m->c1 != 16) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "channel_dims[0]=%d (conv1a kernel is built for 16)", cfg->channel_dims[0]); }
-  if (cfg->nfeatures != 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "nfeatures=%d (only 32 is built)", cfg->nfeatures); }
+  if (m->c1 % 16 || m->c1 > 256) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "channel_dims[0]=%d (conv1a kernels need a multiple of 16, <= 256)", cfg->channel_dims[0]); }
+  if (cfg->nfeatures != 32 && cfg->nfeatures != 64 && cfg->nfeatures != 128) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "nfeatures=%d (32, 64 and 128 are built)", cfg->nfeatures); }
+  if (cfg->downsample != 2 && cfg->downsample != 3) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "downsample=%d (2 and 3 are built)", cfg->downsample); }
   if (cfg->n_classes < 1 || cfg->n_classes > 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "n_classes must be in [1,32]"); }
   int rc = describe(m);
   if (rc != KP2D_OK) { delete m; return rc; }
@@ -1009,7 +1011,7 @@ size_t kp2d_vlad_dim(const kp2d_model* m, int H, int W) {
   if (!m) return 0;
   const kp2d_config& g = m->cfg;
   if (g.global_descriptor != KP2D_GD_NETVLAD) return (size_t)g.encoder_dim * 16;
-  if (g.remove_netvlad) return (size_t)g.encoder_dim * (H / 4) * (W / 4);
+  if (g.remove_netvlad) return (size_t)g.encoder_dim * (H >> g.downsample) * (W >> g.downsample);
   return (size_t)g.num_clusters * g.encoder_dim;
 }
 
@@ -1045,7 +1047,8 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
   if (per == 0) return KP2D_ERR_WORKSPACE;
   if (workspace_bytes < per * nl) return fail(KP2D_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, per * nl);
   const kp2d_config& g = m->cfg;
-  const size_t Hc = H / 4, Wc = W / 4, H2 = H / 2, W2 = W / 2;
+  // cell grid (score / shift) and dense grid (feat / seg / depth: one pixel-shuffle above the cell grid)
+  const size_t Hc = H >> g.downsample, Wc = W >> g.downsample, H2 = 2 * Hc, W2 = 2 * Wc;
   hipStream_t caller = (hipStream_t)stream;
   m->prof_used = 0;
   m->prof_stream = caller;

@@ -22,6 +22,8 @@ int netvlad_nsplit(int S) {
   return n < 1 ? 1 : n;
 }
 
+// NOWN = (cluster, channel) accumulators per thread: K*C <= 256*NOWN
+template <int NOWN>
 __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C, K = a.K, S = a.S;
@@ -38,11 +40,11 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
   for (int e = tid; e < K * C; e += 256) s_w[(e / C) * CP + (e % C)] = a.wa[e];
 
   const int KC_ = K * C;
-  const int nown = (KC_ + 255) / 256;          // <= 16
-  float vacc[16];
-  int vk[16], vc[16];
+  const int nown = (KC_ + 255) / 256;          // <= NOWN
+  float vacc[NOWN];
+  int vk[NOWN], vc[NOWN];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NOWN; ++j) {
     vacc[j] = 0.f;
     const int e = tid + 256 * j;
     vk[j] = (e < KC_) ? e / C : 0;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
     __syncthreads();
     // aggregation
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NOWN; ++j) {
       if (j < nown) {
         float acc = vacc[j];
         const int k = vk[j], c = vc[j];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
   }
   float* dst = a.part + ((size_t)b * a.nsplit + split) * (KC_ + K);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NOWN; ++j) {
     const int e = tid + 256 * j;
     if (j < nown && e < KC_) dst[e] = vacc[j];
   }
@@ -345,7 +347,7 @@ int launch_convap_pool(const PoolArgs& a, hipStream_t s) {
 }
 
 int launch_netvlad(const VladArgs& a, hipStream_t s) {
-  if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 4096 || a.K < 4) return -1100;
+  if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 8192 || a.K < 4) return -1100;
   if ((a.K == 32 || a.K == 64) && a.C <= 64) {
     const int kt = a.K / 32;
     const size_t lds = (size_t)(32 * kt * VP + VT * VP + VT * AP) * sizeof(float);
@@ -353,7 +355,18 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(netvlad_partial_mfma_kernel<1>, dim3(a.nsplit, a.B), dim3(256), lds, s, a);
   } else {
     const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
-    hipLaunchKernelGGL(netvlad_partial_kernel, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+    if (a.K * a.C <= 4096) {
+      hipLaunchKernelGGL(netvlad_partial_kernel<16>, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+    } else {   // TINY_F: 64 clusters x 128 channels, 83 KB of LDS
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&netvlad_partial_kernel<32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(netvlad_partial_kernel<32>, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+    }
   }
   const size_t lds2 = (size_t)(a.K * a.C + 2 * a.K + 8) * sizeof(float);
   hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(256), lds2, s, a);

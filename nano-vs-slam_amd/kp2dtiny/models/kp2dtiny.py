@@ -405,10 +405,12 @@ class _KP2DTinyBase(nn.Module):
         eng = self._get_engine(x.device)
         x = x.contiguous()
         B, _, H, W = x.shape
-        if H % 8 or W % 8:
-            raise ValueError(f"H and W must be divisible by 8 (got {H}x{W}); reference README.md:143")
+        q = 2 * self.cell    # the segmentation head pools the cell grid once more
+        if H % q or W % q:
+            raise ValueError(f"H and W must be divisible by {q} (got {H}x{W}); reference README.md:143")
         dev = x.device
-        Hc, Wc, H2, W2 = H // self.cell, W // self.cell, H // 2, W // 2
+        Hc, Wc = H // self.cell, W // self.cell
+        H2, W2 = 2 * Hc, 2 * Wc        # dense maps sit one pixel-shuffle above the cell grid
         score = torch.empty(B, 1, Hc, Wc, device=dev)
         shift = torch.empty(B, 2, Hc, Wc, device=dev)
         feat = torch.empty(B, self.nfeatures, H2, W2, device=dev)

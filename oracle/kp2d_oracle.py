@@ -29,7 +29,12 @@ import numpy as np
 _S = dict(nfeatures=32, channel_dims=[16, 32, 32, 64, 64, 128], downsample=2, leaky_relu=True, encoder_dim=64)
 _N = dict(nfeatures=32, channel_dims=[16, 24, 24, 48, 48, 96], downsample=2, leaky_relu=True, encoder_dim=48,
           num_clusters=32)
+_D = dict(nfeatures=128, channel_dims=[64, 128, 128, 256, 256, 512], downsample=2, leaky_relu=True, encoder_dim=128,
+          global_descriptor_method="convap")
 V2_CONFIGS = {
+    "D": dict(_D, use_attention=True),                                                     # LARGE_D :168-176
+    "F": dict(nfeatures=64, channel_dims=[16, 32, 64, 128, 128, 256], downsample=3,        # TINY_F :113-119
+              use_attention=False, leaky_relu=True),
     "S": dict(_S, use_attention=False),
     "S_A": dict(_S, use_attention=True),
     "N": dict(_N, use_attention=False),
@@ -39,6 +44,8 @@ V2_CONFIGS = {
     "CONVAP_S_A": dict(_S, use_attention=True, global_descriptor_method="convap"),
 }
 V3_CONFIGS = {
+    "D": dict(_D, use_attention=False),                                                    # LARGE_D_V3 :187-195
+    "D_A": dict(_D, use_attention=True),                                                   # LARGE_D_A_V3 :177-185
     "S": dict(_S, use_attention=False),
     "S_A": dict(_S, use_attention=True),
     # V3_N / V3_N_A carry no num_clusters key -> constructor default 64 (kp2dtiny.py:151-166,690)
@@ -56,6 +63,7 @@ def get_config(name: str, v3: bool = False) -> dict:
         raise ValueError(f"Config {name} not supported by the oracle, choose from {list(table)}")
     cfg = dict(table[name])
     cfg.setdefault("num_clusters", 64)  # kp2dtiny.py:308 / :690
+    cfg.setdefault("encoder_dim", cfg["channel_dims"][3])  # kp2dtiny.py:342-345 / :727-730 (default c4)
     cfg.setdefault("global_descriptor_method", "netvlad")
     cfg.setdefault("remove_netvlad", False)
     cfg.setdefault("depth", False)

@@ -51,6 +51,11 @@ CASES = {
     # depth=True variants (kp2dtiny.py:402-437, segmentation.py:190-193): config name + "+depth"
     "v2_S_depth_64x96": ("S+depth", False, 28, 64, 96, 1, 8, False, 2, False),
     "v3_SA_depth_64x96": ("S_A+depth", True, 19, 64, 96, 1, 8, False, 2, False),
+    # remaining channel sets of get_config (kp2dtiny.py:46-219): LARGE_D (128-d descriptors, ConvAP), TINY_F (cell 8)
+    "v2_D_64x96": ("D", False, 28, 64, 96, 1, 8, False, 2, False),
+    "v2_F_64x96": ("F", False, 28, 64, 96, 1, 8, False, 2, False),
+    "v3_D_64x96": ("D", True, 19, 64, 96, 1, 8, False, 2, False),
+    "v3_DA_64x96": ("D_A", True, 19, 64, 96, 1, 8, False, 2, False),
 }
 
 

@@ -58,7 +58,7 @@ def test_against_reference_golden(name, precision):
     assert np.max(np.abs(post_np["score"] - z["post_score"])) < TOL
     assert np.max(np.abs(post_np["coord"] - z["post_coord"])) < 5e-4
     assert np.max(np.abs(post_np["feat"] - z["post_feat"])) < TOL
-    assert post_np["seg"].dtype == np.int64 and post_np["seg"].shape == (meta["B"], 1, H // 2, W // 2)
+    assert post_np["seg"].dtype == np.int64 and post_np["seg"].shape == (meta["B"], 1, 2 * (H // model.cell), 2 * (W // model.cell))
     clear = z["seg_margin_f16"].astype(np.float32) > 1e-3
     assert np.array_equal(post_np["seg"][:, 0][clear], z["post_seg_u8"][:, 0][clear].astype(np.int64))
     assert (post_np["seg"][:, 0] != z["post_seg_u8"][:, 0]).mean() < 1e-3
@@ -73,7 +73,7 @@ def test_against_reference_golden(name, precision):
             kth = ref_scores[b][ref].min() if len(ref) else 0.7
             bound = 0.7 if len(z[f"keep_idx_{b}"]) <= k else kth
             _same_set(got, ref, ref_scores[b], bound)
-            assert pts.shape == (len(got), 2) and desc.shape == (len(got), 32)
+            assert pts.shape == (len(got), 2) and desc.shape == (len(got), model.nfeatures)
             i = idx.long()
             assert torch.equal(pts[:, 0], post["coord"][b, 0].reshape(-1)[i])
             assert torch.equal(desc[:, 5], post["feat"][b, 5].reshape(-1)[i])
@@ -92,6 +92,8 @@ def test_against_reference_golden(name, precision):
     ("S_A", False, 28, 2, 48, 64),    # attention seg head (V2)
     ("S_A", True, 19, 1, 72, 104),    # attention seg head (V3), ragged
     ("N_A", True, 28, 1, 32, 48),
+    ("F", False, 28, 2, 48, 80),      # TINY_F: three pools (cell 8), 64-d descriptors, 64 x 128 NetVLAD
+    ("D_A", True, 19, 1, 32, 48),     # LARGE_D: 64-wide conv1a, 256-wide attention (head dim 64), 128-d descriptors
 ])
 def test_against_oracle_other_shapes(config, v3, ncls, B, H, W):
     model, sd = product_model(config, v3, ncls)

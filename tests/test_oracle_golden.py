@@ -29,7 +29,7 @@ def test_forward_and_post_match_reference(name):
     assert np.max(np.abs(post["score"] - z["post_score"])) < TOL
     assert np.max(np.abs(post["coord"] - z["post_coord"])) < 2e-4
     assert np.max(np.abs(post["feat"] - z["post_feat"])) < TOL
-    assert post["seg"].dtype == np.int64 and post["seg"].shape == (meta["B"], 1, meta["H"] // 2, meta["W"] // 2)
+    assert post["seg"].dtype == np.int64 and post["seg"].shape == (meta["B"], 1, 2 * (meta["H"] >> cfg["downsample"]), 2 * (meta["W"] >> cfg["downsample"]))
     clear = z["seg_margin_f16"].astype(np.float32) > 1e-3
     assert np.array_equal(post["seg"][:, 0][clear], z["post_seg_u8"][:, 0][clear].astype(np.int64))
     # selectors: the kept / top-k SETS are identical
@@ -39,7 +39,7 @@ def test_forward_and_post_match_reference(name):
         for k in (300, 1000, 4000):
             idx, pts, desc = orc.select_k1(sc, co, ft, 0.7, k)
             assert np.array_equal(idx, z[f"k1_top{k}_idx_{b}"])
-            assert pts.shape == (len(idx), 2) and desc.shape == (len(idx), 32)
+            assert pts.shape == (len(idx), 2) and desc.shape == (len(idx), cfg["nfeatures"])
     k3 = orc.select_k3(post["score"], post["coord"], post["feat"], k=z["k3_idx"].shape[1])
     for b in range(meta["B"]):
         assert_topk_equivalent(k3[0][b], z["post_score"][b].reshape(-1), z["k3_idx"][b])
