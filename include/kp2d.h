@@ -58,7 +58,10 @@ typedef struct kp2d_config {
   int32_t global_descriptor;/* KP2D_GD_NETVLAD / KP2D_GD_GEM / KP2D_GD_CONVAP (vpr.py:53-76)                     */
   int32_t remove_netvlad;   /* to_export configs: "vlad" is the encoder map [B,enc,H/4,W/4] (vpr.py:84)          */
   int32_t depth;            /* depth=True: V2 second seg-like head, V3 third slice + featD (kp2dtiny.py:402-437)  */
+  int32_t upscale_method;   /* KP2D_UP_PIXELSHUFFLE / KP2D_UP_CONVTRANSPOSE (to_mcu, kp2dtiny.py:271-273; base.py:80-117)  */
 } kp2d_config;
+#define KP2D_UP_PIXELSHUFFLE 0
+#define KP2D_UP_CONVTRANSPOSE 1
 #define KP2D_GD_NETVLAD 0
 #define KP2D_GD_GEM 1
 #define KP2D_GD_CONVAP 2

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libkp2d_hip.so")
 KP2D_FWD_EVAL = 1
 PRECISIONS = {"fp32": 0, "f16x3": 1}
 GLOBAL_DESCRIPTORS = {"netvlad": 0, "gem": 1, "convap": 2}
+UPSCALE_METHODS = {"pixelshuffle": 0, "convtranspose": 1}
 
 
 class Kp2dConfig(C.Structure):
@@ -36,6 +37,7 @@ class Kp2dConfig(C.Structure):
         ("global_descriptor", C.c_int32),
         ("remove_netvlad", C.c_int32),
         ("depth", C.c_int32),
+        ("upscale_method", C.c_int32),
     ]
 
 

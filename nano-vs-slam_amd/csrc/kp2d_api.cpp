@@ -58,6 +58,7 @@ struct ConvPack {
   bool bn = false;      // AnnotatedConvBnReLUModel (conv.weight + bn.*) vs plain Conv2d (weight + bias)
   bool shuffle = false; // rows permuted for the PixelShuffle-folding store
   bool bias = true;     // plain conv only: has a .bias tensor
+  bool tconv = false;   // TransposedConvUpsampleModel (base.py:80-117) restated as a pixel-shuffled 3x3 conv (add_tconv)
   int kind = 0;         // 0: 3x3 [co][ci][3][3]   1: 1x1 [co][ci][1][1]   2: 2x2 stride 2 [co][ci][2][2] as 1x1 over 4*ci
   int taps = 9;
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
@@ -186,6 +187,23 @@ void add_conv(kp2d_model* m, const std::string& p, int ci, int co, bool shuffle 
   m->convs.push_back(c);
 }
 
+// TransposedConvUpsampleModel(c) (base.py:80-117): ConvTranspose2d(c, c/4, k3, s2, p1, output_padding 1, no bias)
+// -> BatchNorm2d(c/4) -> (Leaky)ReLU.  Output pixel (2y+a, 2x+b) only sees inputs (y..y+1, x..x+1):
+//   a = 0: in[y] * w[ky=1];   a = 1: in[y] * w[ky=2] + in[y+1] * w[ky=0]      (same along x)
+// so it IS a 3x3 convolution c -> 4*(c/4) with the dy = -1 / dx = -1 taps zero, followed by PixelShuffle(2)
+// (virtual channel 4*co + 2a + b), and runs through the pixel-shuffle store of the conv kernel unchanged.
+void add_tconv(kp2d_model* m, const std::string& p, int c) {
+  add_spec(m, p + ".transposed_conv.weight", {c, c / 4, 3, 3});
+  add_spec(m, p + ".bn.weight", {c / 4});
+  add_spec(m, p + ".bn.bias", {c / 4});
+  add_spec(m, p + ".bn.running_mean", {c / 4});
+  add_spec(m, p + ".bn.running_var", {c / 4});
+  ConvPack k;
+  k.name = p; k.bn = true; k.shuffle = true; k.tconv = true; k.cin = c; k.cout = c;
+  m->conv_index[p] = (int)m->convs.size();
+  m->convs.push_back(k);
+}
+
 // 1x1 conv (kind 1) or 2x2 stride-2 conv (kind 2) routed through the MFMA conv kernel with taps = 1
 void add_pw(kp2d_model* m, const std::string& p, int ci, int co, bool bias, int kind) {
   const int k = kind == 2 ? 2 : 1;
@@ -246,8 +264,10 @@ int describe(kp2d_model* m) {
     add_conv(m, "score_head.convDb", c4, 1);
     add_cbr(m, "loc_head.convDa", c4, c4);
     add_conv(m, "loc_head.convDb", c4, 2);
+    const bool tc0 = g.upscale_method == KP2D_UP_CONVTRANSPOSE;
+    if (tc0) add_tconv(m, "desc_head.upsample", c3 * 4);   // registered first (heads.py:55-56)
     add_cbr(m, "desc_head.convA", c4, c4);
-    add_conv(m, "desc_head.convB", c4, c3 * 4, /*shuffle=*/true);
+    add_conv(m, "desc_head.convB", c4, c3 * 4, /*shuffle=*/!tc0);
     add_cbr(m, "desc_head.confAa", c3 + c4, c4);
     add_conv(m, "desc_head.confBb", c4, g.nfeatures);
   }
@@ -257,15 +277,17 @@ int describe(kp2d_model* m) {
   const int trunk_out = (v3 && g.depth) ? ch + ch / 2 : ch;
   if (g.use_attention && (ch > 256 || (ch % 16)))
     return fail(KP2D_ERR_UNSUPPORTED, "attention width %d (built for <= 256, multiple of 16)", ch);
+  const bool tc = g.upscale_method == KP2D_UP_CONVTRANSPOSE;
+  if (tc && (d1 % 16)) return fail(KP2D_ERR_UNSUPPORTED, "convtranspose upsampling needs channel_dims[5] %% 16 == 0");
   auto seg_like_head = [&](const std::string& P_, int c_out, int width) {
     const std::string L = P_ + ".convs.";
     if (g.use_attention) {
       add_cbr(m, L + "0", c4, ch);
       add_attention_module(m, L + "1", ch);
       add_attention_module(m, L + "2", ch);
-      add_cbr(m, L + "3", ch, d1, true);
+      add_cbr(m, L + "3", ch, d1, !tc);
       add_cbr(m, L + "4", ch + d1 / 4, ch);
-      add_cbr(m, L + "5", ch, d1, true);
+      add_cbr(m, L + "5", ch, d1, !tc);
       add_cbr(m, L + "6", cexp, width);
       add_conv(m, L + "7", P_ == "seg_head" ? last_in : ch, c_out);
     } else {
@@ -273,14 +295,18 @@ int describe(kp2d_model* m) {
       add_cbr(m, L + "1", ch, ch);
       add_cbr(m, L + "2", ch, ch);
       add_cbr(m, L + "3", ch, ch);
-      add_cbr(m, L + "4", ch, d1, true);
+      add_cbr(m, L + "4", ch, d1, !tc);
       add_cbr(m, L + "5", ch + d1 / 4, ch);
-      add_cbr(m, L + "6", ch, d1, true);
+      add_cbr(m, L + "6", ch, d1, !tc);
       add_cbr(m, L + "7", cexp, width);
       add_conv(m, L + "8", P_ == "seg_head" ? last_in : ch, c_out);
     }
   };
+  auto upsamplers = [&](const std::string& P_) {   // registered after convs / featB / featD (segmentation.py:113-118)
+    if (tc) { add_tconv(m, P_ + ".upsample", d1); add_tconv(m, P_ + ".upsample2", d1); }
+  };
   seg_like_head("seg_head", g.n_classes, trunk_out);
+  if (!v3) upsamplers("seg_head");
   if (v3) {
     add_conv(m, "seg_head.featB", ch / 2, g.nfeatures);
     if (g.depth) {   // Conv2d(dim_split, 1, bias=False): segmentation.py:281-284
@@ -290,8 +316,10 @@ int describe(kp2d_model* m) {
       m->conv_index[c.name] = (int)m->convs.size();
       m->convs.push_back(c);
     }
+    upsamplers("seg_head");
   } else if (g.depth) {
     seg_like_head("depth_head", 1, ch);   // kp2dtiny.py:402-437: a second full segmentation head with one output
+    upsamplers("depth_head");
   }
   add_cbr(m, "vlad_head.convlad1", c4, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad2", g.encoder_dim, g.encoder_dim);
@@ -364,9 +392,32 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
     bn_fold(m, "backbone.conv1a.bn", c1, &blob[m->conv1a_sc], &blob[m->conv1a_sh]);
   }
   for (const auto& c : m->convs) {
-    const auto& w = *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][ci][k][k]
+    std::vector<float> wvirt;
+    if (c.tconv) {
+      // virtual 3x3 weight [4*co + 2a + b][ci][ty][tx] of the transposed convolution (see add_tconv)
+      const auto& wt = *host_get(m, c.name + ".transposed_conv.weight");   // [ci][co][ky][kx]
+      const int cq4 = c.cout / 4;
+      wvirt.assign((size_t)c.cout * c.cin * 9, 0.f);
+      auto kmap = [](int par, int t) { return par == 0 ? (t == 1 ? 1 : -1) : (t == 1 ? 2 : (t == 2 ? 0 : -1)); };
+      for (int co = 0; co < cq4; ++co)
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b)
+            for (int ci = 0; ci < c.cin; ++ci)
+              for (int ty = 0; ty < 3; ++ty)
+                for (int tx = 0; tx < 3; ++tx) {
+                  const int ky = kmap(a, ty), kx = kmap(b, tx);
+                  if (ky < 0 || kx < 0) continue;
+                  wvirt[((size_t)(4 * co + 2 * a + b) * c.cin + ci) * 9 + ty * 3 + tx] =
+                      wt[(((size_t)ci * cq4 + co) * 3 + ky) * 3 + kx];
+                }
+    }
+    const auto& w = c.tconv ? wvirt : *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][ci][k][k]
     std::vector<float> sc(c.cout), sh(c.cout);
-    if (c.bn) {
+    if (c.tconv) {
+      std::vector<float> s4(c.cout / 4), h4(c.cout / 4);
+      bn_fold(m, c.name + ".bn", c.cout / 4, s4.data(), h4.data());
+      for (int i = 0; i < c.cout; ++i) { sc[i] = s4[i / 4]; sh[i] = h4[i / 4]; }
+    } else if (c.bn) {
       bn_fold(m, c.name + ".bn", c.cout, sc.data(), sh.data());
     } else {
       const std::vector<float>* b = c.bias ? host_get(m, c.name + ".bias") : nullptr;
@@ -726,8 +777,19 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
     Act d2 = P.alloc(cB.cout / 4, H2, W2);
     d2.s16 = P.s16_mode;
-    P.out_s16[0] = d2.s16 ? 1 : 0;
-    P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+    if (g.upscale_method == KP2D_UP_CONVTRANSPOSE) {
+      // convB at the cell grid, then the transposed-conv upsampler as a pixel-shuffled 3x3 conv (heads.py:96-98)
+      Act db = P.alloc(cB.cout, Hc, Wc);
+      db.s16 = P.s16_mode;
+      P.out_s16[0] = db.s16 ? 1 : 0;
+      P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_NHWC, P.dry ? nullptr : P.ptr(db), db.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+      P.out_s16[0] = d2.s16 ? 1 : 0;
+      P.conv("desc_head.upsample", db, db.C, 0, nullptr, lk, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+      P.release(db);
+    } else {
+      P.out_s16[0] = d2.s16 ? 1 : 0;
+      P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+    }
     P.out_s16[0] = 0;
     P.release(d1);
     Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
@@ -738,6 +800,15 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
 
   // ---- segmentation head: segmentation.py:126-157 (V2), :321-347 (V3), :442-466 (V2 att), :588-619 (V3 att) ----
   // trunk(prefix) runs everything up to the last CBR(c_exp -> width) and returns it plus the name of the final conv
+  // CBR(ch -> d1) + 2x upsampling: PixelShuffle folded into the store, or (to_mcu) the CBR at its own resolution
+  // followed by TransposedConvUpsampleModel as a second, pixel-shuffled conv (segmentation.py:139-147)
+  auto upconv = [&](const std::string& cname, const std::string& uname, const Act& in) -> Act {
+    if (g.upscale_method != KP2D_UP_CONVTRANSPOSE) return P.cbr(cname, in, nullptr, ST_SHUFFLE);
+    Act t = P.cbr(cname, in, nullptr, ST_NHWC);
+    Act u = P.cbr(uname, t, nullptr, ST_SHUFFLE);
+    P.release(t);
+    return u;
+  };
   auto trunk = [&](const std::string& hp, std::string* last) -> Act {
     const std::string L = hp + ".convs.";
     Act g5{};
@@ -748,7 +819,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.release(g0);
       Act a2 = P.attention_module(L + "2", a1, false, /*s16out=*/true);          // feeds convs.3
       P.release(a1);
-      Act g4 = P.cbr(L + "3", a2, nullptr, ST_SHUFFLE);
+      Act g4 = upconv(L + "3", hp + ".upsample", a2);
       P.release(a2);
       g5 = P.cbr(L + "4", g4, &xb, ST_NHWC);
       P.release(g4);
@@ -761,13 +832,13 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.release(g1);
       Act g3 = P.cbr(L + "3", g2, nullptr, ST_NHWC);
       P.release(g2);
-      Act g4 = P.cbr(L + "4", g3, nullptr, ST_SHUFFLE);
+      Act g4 = upconv(L + "4", hp + ".upsample", g3);
       P.release(g3);
       g5 = P.cbr(L + "5", g4, &xb, ST_NHWC);
       P.release(g4);
       i = 6;
     }
-    Act g6 = P.cbr(L + std::to_string(i), g5, nullptr, ST_SHUFFLE);
+    Act g6 = upconv(L + std::to_string(i), hp + ".upsample2", g5);
     P.release(g5);
     Act g7 = P.cbr(L + std::to_string(i + 1), g6, &skip, ST_NHWC);
     P.release(g6);

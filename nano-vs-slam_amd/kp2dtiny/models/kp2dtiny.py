@@ -123,9 +123,26 @@ class _SimpleTaskHead(_Holder):
         self.convDb = nn.Conv2d(ch, co, 3, 1, 1)
 
 
-class _UpscaleHead(_Holder):
-    def __init__(self, c0, c1, c2, c3, c4, c5, mom):
+class _TConvUp(_Holder):
+    """Parameters of TransposedConvUpsampleModel (reference modules/base.py:80-117), the ``to_mcu`` upsampler."""
+
+    def __init__(self, c):
         super().__init__()
+        self.transposed_conv = nn.ConvTranspose2d(c, c // 4, 3, stride=2, padding=1, output_padding=1, bias=False)
+        self.bn = nn.BatchNorm2d(c // 4, momentum=0.1)
+
+
+def _check_upscale(method):
+    if method not in _lib.UPSCALE_METHODS:
+        raise NotImplementedError("Upscale method not implemented")      # heads.py:58 / segmentation.py:120
+
+
+class _UpscaleHead(_Holder):
+    def __init__(self, c0, c1, c2, c3, c4, c5, mom, upscale_method="pixelshuffle"):
+        super().__init__()
+        _check_upscale(upscale_method)
+        if upscale_method == "convtranspose":
+            self.upsample = _TConvUp(c2)       # registered before the convolutions (heads.py:53-58)
         self.convA = _CBR(c0, c1, mom)
         self.convB = nn.Conv2d(c1, c2, 3, 1, 1)
         self.confAa = _CBR(c3, c4, mom)
@@ -177,8 +194,10 @@ class _AttentionModule(_Holder):
 class _SegHead(_Holder):
     """Parameters of the four segmentation heads (reference modules/decoders/segmentation.py)."""
 
-    def __init__(self, c_in, c_hidden, c_exp, c_out, d1, mom, attention, n_feat=None, depth=False):
+    def __init__(self, c_in, c_hidden, c_exp, c_out, d1, mom, attention, n_feat=None, depth=False,
+                 upscale_method="pixelshuffle"):
         super().__init__()
+        _check_upscale(upscale_method)
         fused = n_feat is not None          # V3 "decoder fusion": feat + seg from one trunk
         last_in = c_hidden // 2 if fused else c_hidden
         c_hidden_b = c_hidden + c_hidden // 2 if (fused and depth) else c_hidden   # segmentation.py:190-193
@@ -196,6 +215,8 @@ class _SegHead(_Holder):
             self.featB = nn.Conv2d(c_hidden // 2, n_feat, 3, 1, 1)
             if depth:
                 self.featD = nn.Conv2d(c_hidden // 2, 1, 3, 1, 1, bias=False)
+        if upscale_method == "convtranspose":       # segmentation.py:116-118 / :295-297 / :432-434 / :569-571
+            self.upsample, self.upsample2 = _TConvUp(d1), _TConvUp(d1)
 
     def freeze(self, except_last_layer=False):
         for p in self.parameters():
@@ -324,14 +345,11 @@ class _KP2DTinyBase(nn.Module):
         cfg.global_descriptor = _lib.GLOBAL_DESCRIPTORS[self.global_descriptor_method]
         cfg.remove_netvlad = int(bool(self.remove_netvlad))
         cfg.depth = int(bool(self.depth))
+        cfg.upscale_method = _lib.UPSCALE_METHODS[self.upscale_method]
         return cfg
 
     def _check_built(self):
-        why = None
-        if self.upscale_method != "pixelshuffle":
-            why = f"upscale_method={self.upscale_method!r} (to_mcu path)"
-        if why:
-            raise NotImplementedError(f"{why} is outside the path built so far (DESIGN.md, 'out of scope / next')")
+        pass
 
     def _weights_signature(self):
         return tuple((id(t), t._version) for t in self.state_dict(keep_vars=True).values())
@@ -540,10 +558,10 @@ class KP2DTinyV2(_KP2DTinyBase):
         self.backbone = _BackBone(3, c1, c2, c3, c4, mom)
         self.score_head = _SimpleTaskHead(c4, c4, 1, mom)
         self.loc_head = _SimpleTaskHead(c4, c4, 2, mom)
-        self.desc_head = _UpscaleHead(c4, c4, c3 * 4, c3 + c4, c4, nfeatures, mom)
-        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention)
+        self.desc_head = _UpscaleHead(c4, c4, c3 * 4, c3 + c4, c4, nfeatures, mom, upscale_method)
+        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, upscale_method=upscale_method)
         if depth:
-            self.depth_head = _SegHead(c4, c5, c4 + c3, 1, d1, mom, use_attention)
+            self.depth_head = _SegHead(c4, c5, c4 + c3, 1, d1, mom, use_attention, upscale_method=upscale_method)
         self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # reference force-sets this (kp2dtiny.py:456)
@@ -575,7 +593,8 @@ class KP2DTinyV3(_KP2DTinyBase):
         mom = bn_momentum
         self.backbone = _BackBone(3, c1, c2, c3, c4, 0.1)
         self.score_loc_head = _SimpleTaskHead(c4, c4, 3, mom)
-        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures, depth=depth)
+        self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures, depth=depth,
+                                 upscale_method=upscale_method)
         self.vlad_head = _VPRHead(c4, self.encoder_dim, num_clusters, mom, global_descriptor_method, remove_netvlad)
         self.cell = pow(2, self.downsample)
         self.training = True                       # kp2dtiny.py:813

@@ -58,6 +58,10 @@ V3_CONFIGS = {
 
 
 def get_config(name: str, v3: bool = False) -> dict:
+    """``name`` may carry test-fixture suffixes: "+depth" (constructor depth=True) and "+mcu" (tiny_factory
+    to_mcu=True: upscale_method="convtranspose", leaky_relu=False — kp2dtiny.py:271-273)."""
+    mods = name.split("+")[1:]
+    name = name.split("+")[0]
     table = V3_CONFIGS if v3 else V2_CONFIGS
     if name not in table:
         raise ValueError(f"Config {name} not supported by the oracle, choose from {list(table)}")
@@ -67,6 +71,11 @@ def get_config(name: str, v3: bool = False) -> dict:
     cfg.setdefault("global_descriptor_method", "netvlad")
     cfg.setdefault("remove_netvlad", False)
     cfg.setdefault("depth", False)
+    cfg.setdefault("upscale_method", "pixelshuffle")   # "convtranspose" under to_mcu (kp2dtiny.py:271-273)
+    if "depth" in mods:
+        cfg["depth"] = True
+    if "mcu" in mods:
+        cfg["upscale_method"], cfg["leaky_relu"] = "convtranspose", False
     cfg["v3"] = v3
     return cfg
 
@@ -90,6 +99,18 @@ def _conv_shapes(prefix, ci, co, k=3, bias=True, groups=1):
     if bias:
         d[f"{prefix}.bias"] = (co,)
     return d
+
+
+def _tconv_shapes(prefix, c):
+    """TransposedConvUpsampleModel(c): modules/base.py:80-117."""
+    return {
+        f"{prefix}.transposed_conv.weight": (c, c // 4, 3, 3),
+        f"{prefix}.bn.weight": (c // 4,),
+        f"{prefix}.bn.bias": (c // 4,),
+        f"{prefix}.bn.running_mean": (c // 4,),
+        f"{prefix}.bn.running_var": (c // 4,),
+        f"{prefix}.bn.num_batches_tracked": (),
+    }
 
 
 def _attmod_shapes(prefix, c):
@@ -128,7 +149,9 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
         s.update(_conv_shapes("score_head.convDb", c4, 1))
         s.update(_cbr_shapes("loc_head.convDa", c4, c4))
         s.update(_conv_shapes("loc_head.convDb", c4, 2))
-        # UpscaleHead(c4, c4, c3*4, c3+c4, c4, nfeatures): kp2dtiny.py:377-388
+        # UpscaleHead(c4, c4, c3*4, c3+c4, c4, nfeatures): kp2dtiny.py:377-388; upsample registered first (heads.py:53-58)
+        if cfg.get("upscale_method", "pixelshuffle") == "convtranspose":
+            s.update(_tconv_shapes("desc_head.upsample", c3 * 4))
         s.update(_cbr_shapes("desc_head.convA", c4, c4))
         s.update(_conv_shapes("desc_head.convB", c4, c3 * 4))
         s.update(_cbr_shapes("desc_head.confAa", c3 + c4, c4))
@@ -136,6 +159,12 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
     # seg head: (c_in=c4, c_hidden=c5, c_exp=c4+c3, c_out=nClasses, d1)
     ch, cexp = c5, c4 + c3
     depth = cfg.get("depth", False)
+    tconv = cfg.get("upscale_method", "pixelshuffle") == "convtranspose"
+
+    def upsamplers(prefix):      # registered after convs / featB / featD (segmentation.py:113-118, :290-297)
+        if tconv:
+            s.update(_tconv_shapes(f"{prefix}.upsample", d1))
+            s.update(_tconv_shapes(f"{prefix}.upsample2", d1))
 
     def seg_like(prefix, c_out, width, last_in):
         P = f"{prefix}.convs"
@@ -165,10 +194,13 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
         s.update(_conv_shapes("seg_head.featB", ch // 2, nf))
         if depth:
             s.update(_conv_shapes("seg_head.featD", ch // 2, 1, bias=False))
+        upsamplers("seg_head")
     else:
         seg_like("seg_head", n_classes, ch, ch)
+        upsamplers("seg_head")
         if depth:
             seg_like("depth_head", 1, ch, ch)            # kp2dtiny.py:402-437
+            upsamplers("depth_head")
     for i in (1, 2, 3):
         s.update(_cbr_shapes(f"vlad_head.convlad{i}", c4 if i == 1 else enc, enc))
     method = cfg.get("global_descriptor_method", "netvlad")
@@ -271,6 +303,29 @@ def pixel_shuffle2(x):
     return np.ascontiguousarray(x).reshape(B, C // 4, 2 * H, 2 * W)
 
 
+def conv_transpose2d_3x3_s2(x, w):
+    """ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1, bias=False) — base.py:93-101, scatter form:
+    out[2*iy - 1 + ky, 2*ix - 1 + kx] += x[iy, ix] * w[ci, co, ky, kx]; output is exactly 2H x 2W."""
+    B, C, H, W = x.shape
+    Co = w.shape[1]
+    full = np.zeros((B, Co, 2 * H + 2, 2 * W + 2), x.dtype)      # index = output coordinate + 1
+    xf = x.reshape(B, C, H * W)
+    for ky in range(3):
+        for kx in range(3):
+            contrib = np.matmul(w[:, :, ky, kx].T.astype(x.dtype), xf).reshape(B, Co, H, W)
+            full[:, :, ky:ky + 2 * H:2, kx:kx + 2 * W:2] += contrib
+    return np.ascontiguousarray(full[:, :, 1:2 * H + 1, 1:2 * W + 1])
+
+
+def upsample2(x, p, prefix, cfg):
+    """heads.py:53-58 / segmentation.py:113-118: PixelShuffle(2), or TransposedConvUpsampleModel.forward
+    (base.py:109-117: transposed conv -> BN -> (Leaky)ReLU) when upscale_method == "convtranspose"."""
+    if cfg.get("upscale_method", "pixelshuffle") == "pixelshuffle":
+        return pixel_shuffle2(x)
+    y = conv_transpose2d_3x3_s2(x, p[f"{prefix}.transposed_conv.weight"])
+    return act(batchnorm_eval(y, p, f"{prefix}.bn"), cfg["leaky_relu"])
+
+
 def softmax(x, axis):
     m = x.max(axis=axis, keepdims=True)
     e = np.exp(x - m)
@@ -325,11 +380,11 @@ def simple_task_head(x, p, prefix, lk):
     return conv_b(cbr(x, p, f"{prefix}.convDa", lk), p, f"{prefix}.convDb")
 
 
-def upscale_head(x, skip, p, prefix, lk):
-    """UpscaleHead.forward (pixelshuffle) — modules/decoders/heads.py:91-104."""
+def upscale_head(x, skip, p, prefix, lk, cfg=None):
+    """UpscaleHead.forward — modules/decoders/heads.py:91-104."""
     x = cbr(x, p, f"{prefix}.convA", lk)
     x = conv_b(x, p, f"{prefix}.convB")
-    x = pixel_shuffle2(x)
+    x = upsample2(x, p, f"{prefix}.upsample", cfg or {})
     x = np.concatenate([x, skip], axis=1)
     x = cbr(x, p, f"{prefix}.confAa", lk)
     return conv_b(x, p, f"{prefix}.confBb")
@@ -414,10 +469,10 @@ def seg_trunk(x, skip, p, cfg, taps=None, head="seg_head"):
         seg = cbr(seg, p, f"{P}.3", lk)
         seg = cbr(seg, p, f"{P}.4", lk)
         i = 5
-    seg = np.concatenate([pixel_shuffle2(seg), x], axis=1)
+    seg = np.concatenate([upsample2(seg, p, f"{head}.upsample", cfg), x], axis=1)
     seg = cbr(seg, p, f"{P}.{i}", lk)
     seg = cbr(seg, p, f"{P}.{i + 1}", lk)
-    seg = np.concatenate([pixel_shuffle2(seg), skip], axis=1)
+    seg = np.concatenate([upsample2(seg, p, f"{head}.upsample2", cfg), skip], axis=1)
     seg = cbr(seg, p, f"{P}.{i + 2}", lk)
     if taps is not None:
         taps[f"{head}.trunk"] = seg
@@ -531,7 +586,7 @@ def forward(x, p, cfg, taps=None, eval_mode=True):
     else:
         score = sigmoid(simple_task_head(xb, p, "score_head", lk))
         shift = np.tanh(simple_task_head(xb, p, "loc_head", lk))
-        feat = upscale_head(xb, skip, p, "desc_head", lk)
+        feat = upscale_head(xb, skip, p, "desc_head", lk, cfg)
         seg = seg_head_v2(xb, skip, p, cfg, taps)
     vlad = vpr_head(xb, p, cfg, taps)
     out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}

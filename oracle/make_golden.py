@@ -56,18 +56,24 @@ CASES = {
     "v2_F_64x96": ("F", False, 28, 64, 96, 1, 8, False, 2, False),
     "v3_D_64x96": ("D", True, 19, 64, 96, 1, 8, False, 2, False),
     "v3_DA_64x96": ("D_A", True, 19, 64, 96, 1, 8, False, 2, False),
+    # to_mcu=True (kp2dtiny.py:271-273): TransposedConvUpsampleModel instead of PixelShuffle, ReLU.  The reference's
+    # get_config MUTATES its module-level table for to_mcu, so these cases must run in their own process (--only).
+    "v2_S_mcu_64x96": ("S+mcu", False, 28, 64, 96, 2, 8, False, 2, False),
+    "v3_SA_mcu_64x96": ("S_A+mcu", True, 19, 64, 96, 1, 8, False, 2, False),
+    "v2_NA_mcu_depth_64x96": ("N_A+mcu+depth", False, 28, 64, 96, 1, 8, False, 2, False),
 }
 
 
 def build_reference(config, v3, n_classes):
     from src.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory
+    base, *mods = config.split("+")
     with contextlib.redirect_stdout(io.StringIO()):
-        if config.endswith("+depth"):
+        if "depth" in mods:
             import copy
-            conf = copy.deepcopy(get_config(config[:-6], v3=v3))
+            conf = copy.deepcopy(get_config(base, to_mcu="mcu" in mods, v3=v3))
             model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**conf, nClasses=n_classes, depth=True)
         else:
-            model = tiny_factory(config, n_classes, v3=v3)
+            model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = spread_state_dict(shapes)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
@@ -89,8 +95,7 @@ def gaps(score_flat, ks, thr=0.7):
 def run_case(name, out_dir):
     config, v3, ncls, H, W, B, seed, smooth, stride, want_taps = CASES[name]
     model, shapes, sd = build_reference(config, v3, ncls)
-    cfg = orc.get_config(config.replace("+depth", ""), v3)
-    cfg["depth"] = config.endswith("+depth")
+    cfg = orc.get_config(config, v3)
     # the oracle's own key/shape table must equal the reference's registration order
     mine = orc.state_dict_shapes(cfg, ncls)
     assert list(mine.items()) == [(k, tuple(s)) for k, s in shapes.items()], f"{name}: state-dict layout drift"

@@ -29,8 +29,7 @@ def golden_inputs(meta):
     """Regenerate the (weights, frames) a fixture was produced from — nothing but seeds is stored."""
     from oracle import kp2d_oracle as orc
     from oracle.weights import spread_state_dict, synthetic_frames
-    cfg = orc.get_config(meta["config"].replace("+depth", ""), meta["v3"])
-    cfg["depth"] = meta["config"].endswith("+depth")
+    cfg = orc.get_config(meta["config"], meta["v3"])      # understands the "+depth" / "+mcu" fixture suffixes
     shapes = orc.state_dict_shapes(cfg, meta["n_classes"])
     sd = spread_state_dict(shapes, seed=meta["weight_seed"], head_gain=meta["head_gain"])
     x = synthetic_frames(meta["B"], meta["H"], meta["W"], meta["frame_seed"], meta["smooth"])
@@ -42,11 +41,13 @@ def product_model(config, v3, n_classes, device="cuda:0", seed=1234):
     import torch
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from oracle.weights import spread_state_dict
-    if config.endswith("+depth"):
+    base, *mods = config.split("+")
+    if "depth" in mods:
         from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config
-        model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**get_config(config[:-6], v3=v3), nClasses=n_classes, depth=True)
+        model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**get_config(base, to_mcu="mcu" in mods, v3=v3),
+                                                   nClasses=n_classes, depth=True)
     else:
-        model = tiny_factory(config, n_classes, v3=v3)
+        model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = spread_state_dict(shapes, seed=seed)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)

@@ -79,12 +79,28 @@ def test_no_cpu_path():
 
 
 def test_unbuilt_variants_raise_not_fallback():
-    m = K.tiny_factory("S", 28, to_mcu=True)
-    with pytest.raises(NotImplementedError):
-        m._check_built()
+    with pytest.raises(NotImplementedError):       # heads.py:58 / segmentation.py:120
+        K.KP2DTinyV2(**K.get_config("S"), nClasses=28, upscale_method="bilinear")
     K.KP2DTinyV2(**K.get_config("S"), nClasses=28, depth=True)._check_built()      # depth heads are built
     d = K.KP2DTinyV3(**K.get_config("S", v3=True), nClasses=19, depth=True)
     assert d.seg_head.convs[7].conv.weight.shape[0] == 96 and d.seg_head.featD.bias is None
+
+
+@pytest.mark.parametrize("name,v3", [("S", False), ("S_A", False), ("N", True), ("S_A", True)])
+def test_to_mcu_state_dict_layout(name, v3):
+    """to_mcu=True: TransposedConvUpsampleModel parameters in the reference's registration order, ReLU."""
+    m = K.tiny_factory(name, 28, to_mcu=True, v3=v3)
+    assert m.upscale_method == "convtranspose" and m.leaky_relu is False
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == list(orc.state_dict_shapes(orc.get_config(name + "+mcu", v3), 28).items())
+    assert K.get_config(name, v3=v3).get("upscale_method", "pixelshuffle") == "pixelshuffle"   # table not mutated
+
+
+@pytest.mark.parametrize("name,v3", [("D", False), ("F", False), ("D", True), ("D_A", True)])
+def test_large_and_tiny_f_state_dict_layout(name, v3):
+    m = K.tiny_factory(name, 28, v3=v3)
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == list(orc.state_dict_shapes(orc.get_config(name, v3), 28).items())
 
 
 @pytest.mark.parametrize("name,v3", [("GEM_S_A", False), ("GEM_N", False), ("CONVAP_S_A", False), ("CONVAP_S_A", True)])
