@@ -68,6 +68,9 @@ typedef struct kp2d_config {
 
 /* kp2d_forward flags */
 #define KP2D_FWD_EVAL 1u    /* model.training is False: V3 applies Softmax2d to seg (kp2dtiny.py:942-943) */
+#define KP2D_FWD_ONLY_ENCODER 2u /* model.only_encoder(x) (kp2dtiny.py:515-518, vpr.py:78-89): backbone + convlad1-3 only;
+                                    vlad = channel-wise L2-normalised encoder map [B,enc,Hc,Wc] (raw map when
+                                    remove_netvlad); score/shift/feat/seg/depth are not written and may be NULL */
 
 const char* kp2d_last_error(void);
 int32_t kp2d_abi_version(void);

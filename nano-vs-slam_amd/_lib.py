@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkp2d_hip.so")
 
 KP2D_FWD_EVAL = 1
+KP2D_FWD_ONLY_ENCODER = 2
 PRECISIONS = {"fp32": 0, "f16x3": 1}
 GLOBAL_DESCRIPTORS = {"netvlad": 0, "gem": 1, "convap": 2}
 UPSCALE_METHODS = {"pixelshuffle": 0, "convtranspose": 1}

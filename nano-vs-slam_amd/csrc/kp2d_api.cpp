@@ -760,8 +760,10 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   P.release(t4a);
   const int Hc = xb.H, Wc = xb.W, H2 = skip.H, W2 = skip.W;
 
+  const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;   // only_encoder(): skip every head but the VPR encoder
   // ---- score / location heads (heads.py:28-35; sigmoid/tanh kp2dtiny.py:574-575, :927-935) ----
-  if (v3) {
+  if (only_enc) {
+  } else if (v3) {
     Act s1 = P.cbr("score_loc_head.convDa", xb, nullptr, ST_NHWC);
     P.conv("score_loc_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID0_TANH, ST_NCHW, o.score, 0, 0, o.shift, 0, 0, 1, Hc, Wc);
     P.release(s1);
@@ -845,7 +847,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     *last = L + std::to_string(i + 2);
     return g7;
   };
-  {
+  if (!only_enc) {
     std::string last;
     Act g7 = trunk("seg_head", &last);
     if (v3) {
@@ -861,7 +863,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     }
     P.release(g7);
   }
-  if (!v3 && g.depth) {   // depth = depth_head(x, skip).sigmoid()  (kp2dtiny.py:588-590)
+  if (!only_enc && !v3 && g.depth) {   // depth = depth_head(x, skip).sigmoid()  (kp2dtiny.py:588-590)
     std::string last;
     Act g7 = trunk("depth_head", &last);
     P.conv(last, g7, g7.C, 0, nullptr, ACT_SIGMOID, ST_NCHW, o.depth, 0, 0, nullptr, 0, 0, 1, H2, W2);
@@ -876,7 +878,14 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // NetVLAD reads fp32
     P.release(v2);
     const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
-    if (g.global_descriptor == KP2D_GD_GEM) {
+    if (only_enc || g.remove_netvlad) {
+      // vpr.py:84-87: remove_netvlad (to_export) returns the encoder map itself whatever the pooler;
+      // only_encoder=True returns l2(map).  Both leave as the NCHW map.
+      if (!P.dry && P.rc == KP2D_OK) {
+        if (!g.remove_netvlad) P.check(launch_l2norm_channels(P.ptr(v3a), (long)B * S, C, P.stream), "vlad_head.l2");
+        P.check(launch_nhwc_to_nchw(P.ptr(v3a), o.vlad, B, C, S, C, 0, P.stream), "vlad_head (encoder map)");
+      }
+    } else if (g.global_descriptor == KP2D_GD_GEM) {
       if (!P.dry && P.rc == KP2D_OK) {
         PoolArgs a{P.ptr(v3a), m->blob + m->vecs.at("vlad_head.netvlad.p").off, o.vlad, B, C, Hc, Wc};
         P.prof_begin("vlad_head.netvlad", "gem", 4.0 * B * S * C, 4.0 * B * S * C);
@@ -892,10 +901,6 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
         P.prof_end();
       }
       P.release(cp);
-    } else if (g.remove_netvlad) {
-      // to_export: the reference returns the encoder map itself (vpr.py:84), NCHW
-      if (!P.dry && P.rc == KP2D_OK)
-        P.check(launch_nhwc_to_nchw(P.ptr(v3a), o.vlad, B, C, S, C, 0, P.stream), "vlad_head (encoder map)");
     } else {
       const int ns = netvlad_nsplit(S);
       Act part{};
@@ -1081,8 +1086,8 @@ static void schedule(const kp2d_model* m, int B, int H, int W, int* lanes, int* 
 size_t kp2d_vlad_dim(const kp2d_model* m, int H, int W) {
   if (!m) return 0;
   const kp2d_config& g = m->cfg;
+  if (g.remove_netvlad) return (size_t)g.encoder_dim * (H >> g.downsample) * (W >> g.downsample);   // vpr.py:84
   if (g.global_descriptor != KP2D_GD_NETVLAD) return (size_t)g.encoder_dim * 16;
-  if (g.remove_netvlad) return (size_t)g.encoder_dim * (H >> g.downsample) * (W >> g.downsample);
   return (size_t)g.num_clusters * g.encoder_dim;
 }
 
@@ -1106,8 +1111,10 @@ size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
 int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
                  float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
                  void* stream) {
-  if (!m || !x || !score || !shift || !feat || !seg || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
-  if (m->cfg.depth && !depth) return fail(KP2D_ERR_ARG, "depth=1 model needs the depth output");
+  const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;
+  if (!m || !x || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
+  if (!only_enc && (!score || !shift || !feat || !seg)) return fail(KP2D_ERR_ARG, "null argument");
+  if (!only_enc && m->cfg.depth && !depth) return fail(KP2D_ERR_ARG, "depth=1 model needs the depth output");
   if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised (kp2d_finalize_weights / kp2d_import_packed)");
   int rc = validate_shape(m, B, H, W);
   if (rc != KP2D_OK) return rc;
@@ -1147,11 +1154,11 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     P.arena.reset(per);
     FwdOut o{};
     o.x = x + (size_t)b0 * 3 * H * W;
-    o.score = score + (size_t)b0 * Hc * Wc;
-    o.shift = shift + (size_t)b0 * 2 * Hc * Wc;
-    o.feat = feat + (size_t)b0 * g.nfeatures * H2 * W2;
-    o.seg = seg + (size_t)b0 * g.n_classes * H2 * W2;
-    o.vlad = vlad + (size_t)b0 * kp2d_vlad_dim(m, H, W);
+    o.score = score ? score + (size_t)b0 * Hc * Wc : nullptr;
+    o.shift = shift ? shift + (size_t)b0 * 2 * Hc * Wc : nullptr;
+    o.feat = feat ? feat + (size_t)b0 * g.nfeatures * H2 * W2 : nullptr;
+    o.seg = seg ? seg + (size_t)b0 * g.n_classes * H2 * W2 : nullptr;
+    o.vlad = vlad + (size_t)b0 * (only_enc ? (size_t)g.encoder_dim * Hc * Wc : kp2d_vlad_dim(m, H, W));
     o.depth = depth ? depth + (size_t)b0 * H2 * W2 : nullptr;
     build(P, o, flags);
     if (P.rc != KP2D_OK) return P.rc;

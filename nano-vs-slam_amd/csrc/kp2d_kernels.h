@@ -141,6 +141,7 @@ int launch_match(const MatchArgs& a, hipStream_t s);
 
 // ---- small layout / elementwise kernels -----------------------------------------------------
 int launch_preprocess(const unsigned char* src, float* dst, int B, int Hs, int Ws, int H, int W, hipStream_t s);
+int launch_l2norm_channels(float* x, long npix, int C, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s);
 
 }  // namespace kp2d

@@ -315,6 +315,36 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, floa
   }
 }
 
+// L2Norm over channels (modules/base.py:5-11: F.normalize(p=2, dim=1), eps 1e-12), in place on an NHWC map.
+// One wave per pixel, lane = channels lane, lane+64, ... (C <= 256).
+__global__ __launch_bounds__(256) void l2norm_channels_kernel(float* x, long npix, int C) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwave = (long)gridDim.x * 4;
+  for (long p = wave; p < npix; p += nwave) {
+    float v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = lane + 64 * i < C ? x[p * C + lane + 64 * i] : 0.f;
+      ss = fmaf(v[i], v[i], ss);
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < C) x[p * C + lane + 64 * i] = v[i] * inv;
+  }
+}
+
+int launch_l2norm_channels(float* x, long npix, int C, hipStream_t s) {
+  if (C < 1 || C > 256) return -1700;
+  long blocks = (npix + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(l2norm_channels_kernel, dim3((int)blocks), dim3(256), 0, s, x, npix, C);
+  return (int)hipGetLastError();
+}
+
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int istride, int ioff, hipStream_t s) {
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, in, out, C, HW,
                      istride, ioff);

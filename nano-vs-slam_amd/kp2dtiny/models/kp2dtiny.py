@@ -230,8 +230,21 @@ class _NetVLAD(_Holder):
     def __init__(self, num_clusters, dim):
         super().__init__()
         self.num_clusters, self.dim = num_clusters, dim
+        self.alpha = 0
         self.conv = nn.Conv2d(dim, num_clusters, kernel_size=(1, 1), bias=False)
         self.centroids = nn.Parameter(torch.rand(num_clusters, dim))
+
+    def init_params(self, clsts, traindescs):
+        """NetVLAD.init_params, vladv2=False (reference aggregators/netvlad.py:41-56): soft-assignment weights are the
+        unit-norm cluster centres scaled by alpha, alpha chosen so the runner-up cluster gets weight 0.01."""
+        import numpy as np
+        unit = clsts / np.linalg.norm(clsts, axis=1, keepdims=True)
+        dots = np.sort(np.dot(unit, traindescs.T), axis=0)[::-1, :]          # per descriptor, descending
+        self.alpha = (-np.log(0.01) / np.mean(dots[0, :] - dots[1, :])).item()
+        dev = self.centroids.device
+        self.centroids = nn.Parameter(torch.from_numpy(np.ascontiguousarray(clsts)).to(dev))
+        self.conv.weight = nn.Parameter(torch.from_numpy(self.alpha * unit).unsqueeze(2).unsqueeze(3).to(dev))
+        self.conv.bias = None
 
 
 class _GeM(_Holder):
@@ -434,8 +447,8 @@ class _KP2DTinyBase(nn.Module):
         feat = torch.empty(B, self.nfeatures, H2, W2, device=dev)
         seg = torch.empty(B, self.nClasses, H2, W2, device=dev)
         vdim = eng.lib.kp2d_vlad_dim(eng.handle, H, W)
-        vlad = (torch.empty(B, self.encoder_dim, Hc, Wc, device=dev) if self.remove_netvlad and
-                self.global_descriptor_method == "netvlad" else torch.empty(B, vdim, device=dev))
+        vlad = (torch.empty(B, self.encoder_dim, Hc, Wc, device=dev) if self.remove_netvlad
+                else torch.empty(B, vdim, device=dev))
         depth = torch.empty(B, 1, H2, W2, device=dev) if self.depth else None
         ws = eng.workspace(B, H, W, dev)
         flags = 0 if self.training else _lib.KP2D_FWD_EVAL
@@ -515,10 +528,26 @@ class _KP2DTinyBase(nn.Module):
         return None
 
     def init_netvlad(self, clsts, traindescs):
-        raise NotImplementedError("NetVLAD centroid initialisation belongs to training (out of scope)")
+        """Reference: kp2dtiny.py:490-491 -> NetVLAD.init_params (aggregators/netvlad.py:41-77, vladv2=False branch)."""
+        self.vlad_head.netvlad.init_params(clsts, traindescs)
 
     def only_encoder(self, x):
-        raise NotImplementedError("only_encoder() is a training-time helper (utils/netvlad_utils.py) — out of scope")
+        """Reference: kp2dtiny.py:515-518 — backbone + VPR encoder, channel-wise L2-normalised (vpr.py:84-87)."""
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
+            raise ValueError(f"expected float32 [B,3,H,W] input, got {x.dtype} {tuple(x.shape)}")
+        eng = self._get_engine(x.device)
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        q = 2 * self.cell
+        if H % q or W % q:
+            raise ValueError(f"H and W must be divisible by {q} (got {H}x{W})")
+        enc = torch.empty(B, self.encoder_dim, H // self.cell, W // self.cell, device=x.device)
+        ws = eng.workspace(B, H, W, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        null = C.c_void_p()
+        _lib.check(eng.lib.kp2d_forward(eng.handle, _ptr(x), B, H, W, _lib.KP2D_FWD_ONLY_ENCODER, null, null, null, null,
+                                        _ptr(enc), null, _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        return enc
 
 
 def _common_init(self, *, nfeatures, device, channel_dims, bn_momentum, nClasses, num_clusters, downsample,

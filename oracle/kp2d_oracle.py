@@ -521,7 +521,7 @@ def netvlad(x, p, prefix="vlad_head.netvlad", literal=False):
     return l2_normalize(v.reshape(B, -1), axis=1)
 
 
-def vpr_head(x, p, cfg, taps=None):
+def vpr_head(x, p, cfg, taps=None, only_encoder=False):
     """VPRHead.forward — modules/decoders/vpr.py:78-89."""
     lk = cfg["leaky_relu"]
     v = cbr(x, p, "vlad_head.convlad1", lk)
@@ -529,14 +529,32 @@ def vpr_head(x, p, cfg, taps=None):
     v = cbr(v, p, "vlad_head.convlad3", lk)
     if taps is not None:
         taps["vlad_head.enc"] = v
+    if cfg.get("remove_netvlad", False):
+        return v                                    # vpr.py:84: the encoder map itself, NCHW (whatever the pooler)
+    if only_encoder:
+        return l2_normalize(v, axis=1)              # vpr.py:85-86, L2Norm base.py:5-11
     method = cfg.get("global_descriptor_method", "netvlad")
     if method == "gem":
         return gem(v, p)
     if method == "convap":
         return convap(v, p)
-    if cfg.get("remove_netvlad", False):
-        return v                                    # vpr.py:84: the encoder map itself, NCHW
     return netvlad(v, p)
+
+
+def only_encoder(x, p, cfg):
+    """KP2DTinyV2/V3.only_encoder — kp2dtiny.py:515-518 / :869-872."""
+    xb, _ = backbone(x, p, cfg)
+    return vpr_head(xb, p, cfg, only_encoder=True)
+
+
+def netvlad_init_params(clsts, traindescs):
+    """NetVLAD.init_params, vladv2=False — aggregators/netvlad.py:51-63.  Returns (alpha, centroids, conv weight)."""
+    unit = clsts / np.linalg.norm(clsts, axis=1, keepdims=True)
+    dots = np.dot(unit, traindescs.T)
+    dots.sort(0)
+    dots = dots[::-1, :]
+    alpha = float(-np.log(0.01) / np.mean(dots[0, :] - dots[1, :]))
+    return alpha, clsts, (alpha * unit)[:, :, None, None]
 
 
 def gem(x, p, prefix="vlad_head.netvlad", unshuffle=4, eps=1e-6):

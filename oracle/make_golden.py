@@ -158,6 +158,25 @@ def run_case(name, out_dir):
     meta["gaps"] = guard
     for k, v in taps.items():
         arrays["tap:" + k] = v
+    if want_taps:
+        # only_encoder (kp2dtiny.py:515-518) and NetVLAD.init_params (aggregators/netvlad.py:51-63) on seeded inputs;
+        # init_params REPLACES the model's NetVLAD parameters, so it runs last
+        with torch.no_grad():
+            arrays["only_encoder"] = model.only_encoder(torch.from_numpy(x)).numpy().copy()
+        assert np.max(np.abs(orc.only_encoder(x, {k: np.asarray(v) for k, v in sd.items()}, cfg) - arrays["only_encoder"])) < 1e-5
+        g = np.random.default_rng(77)
+        K, C = model.vlad_head.netvlad.num_clusters, model.vlad_head.netvlad.dim
+        clsts = g.standard_normal((K, C)).astype(np.float32)
+        descs = g.standard_normal((500, C)).astype(np.float32)
+        descs /= np.linalg.norm(descs, axis=1, keepdims=True)
+        model.init_netvlad(clsts.copy(), descs.copy())
+        nv = model.vlad_head.netvlad
+        arrays["init_clsts"], arrays["init_descs"] = clsts, descs
+        arrays["init_alpha"] = np.float64(nv.alpha)
+        arrays["init_conv_weight"] = nv.conv.weight.detach().numpy().copy()
+        arrays["init_centroids"] = nv.centroids.detach().numpy().copy()
+        a, c, w = orc.netvlad_init_params(clsts.copy(), descs.copy())
+        assert abs(a - nv.alpha) < 1e-9 * abs(a) and np.array_equal(w, arrays["init_conv_weight"])
 
     # cross-check the numpy oracle against the reference right here (fp32)
     p32 = {k: np.asarray(v) for k, v in sd.items()}

@@ -395,3 +395,42 @@ def test_preprocess_front_end_matches_torch():
     pts, feat, out = inference(model, frames[0], (96, 128), nn_thresh=0.3, top_k=100)
     assert out["score"].shape == (1, 1, 24, 32) and pts.shape[1] == 2 and feat.shape[1] == 32
     assert pts[:, 0].max() <= 200 and pts[:, 1].max() <= 150 and (len(pts) == 0 or pts[:, 0].max() > 128 * 0.9)
+
+
+@pytest.mark.parametrize("name", ["v2_N_32x48_taps", "v3_SA_32x48_taps"])
+def test_only_encoder_matches_reference(name):
+    """model.only_encoder(x): backbone + VPR encoder + channel L2Norm (kp2dtiny.py:515-518), reference fixture."""
+    meta, z = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    model, _ = product_model(meta["config"], meta["v3"], meta["n_classes"])
+    with torch.no_grad():
+        enc = model.only_encoder(torch.from_numpy(x).to(DEV))
+    assert enc.shape == z["only_encoder"].shape
+    assert np.max(np.abs(enc.cpu().numpy() - z["only_encoder"])) < TOL
+    # init_netvlad replaces the NetVLAD parameters; the engine must pick the new tensors up
+    model.init_netvlad(z["init_clsts"].copy(), z["init_descs"].copy())
+    sd2 = dict(sd)
+    sd2["vlad_head.netvlad.conv.weight"], sd2["vlad_head.netvlad.centroids"] = z["init_conv_weight"], z["init_centroids"]
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(DEV))
+    ref = orc.forward(x, sd2, cfg)
+    assert np.max(np.abs(out["vlad"].cpu().numpy() - ref["vlad"])) < 1e-5
+
+
+def test_remove_netvlad_wins_over_pooler():
+    """to_export on a GeM / ConvAP config: VPRHead.forward returns the encoder map (vpr.py:84), pooler unused."""
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from oracle.weights import spread_state_dict
+    model = tiny_factory("GEM_N", 28, to_export=True)
+    sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    model.training = False
+    x = synthetic_frames(1, 32, 48, seed=4)
+    cfg = orc.get_config("GEM_N")
+    cfg["remove_netvlad"] = True
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(DEV))
+    ref = orc.forward(x, sd, cfg)
+    assert out["vlad"].shape == ref["vlad"].shape == (1, 48, 8, 12)
+    assert np.max(np.abs(out["vlad"].cpu().numpy() - ref["vlad"])) < TOL

@@ -134,3 +134,16 @@ def test_seeded_inputs_are_reproducible():
     x = synthetic_frames(2, 16, 24, seed=7)
     assert x.shape == (2, 3, 16, 24) and x.dtype == np.float32 and -1 <= x.min() and x.max() <= 1
     assert np.array_equal(x, synthetic_frames(2, 16, 24, seed=7))
+
+
+def test_init_netvlad_matches_reference_fixture():
+    """Host-side NetVLAD.init_params (no GPU involved): alpha, centroids and soft-assignment weights as the reference."""
+    from conftest import load_golden
+    meta, z = load_golden("v2_N_32x48_taps")
+    m = K.tiny_factory("N", 28)
+    m.init_netvlad(z["init_clsts"].copy(), z["init_descs"].copy())
+    nv = m.vlad_head.netvlad
+    assert abs(nv.alpha - float(z["init_alpha"])) < 1e-9 * abs(nv.alpha)
+    assert np.array_equal(nv.conv.weight.detach().numpy(), z["init_conv_weight"])
+    assert np.array_equal(nv.centroids.detach().numpy(), z["init_centroids"])
+    assert [k for k in m.state_dict() if "netvlad" in k] == ["vlad_head.netvlad.centroids", "vlad_head.netvlad.conv.weight"]

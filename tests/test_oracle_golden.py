@@ -90,3 +90,14 @@ def test_selector_edge_cases():
 def test_get_config_errors():
     with pytest.raises(ValueError):
         orc.get_config("nope")
+
+
+@pytest.mark.parametrize("name", ["v2_N_32x48_taps", "v3_SA_32x48_taps"])
+def test_only_encoder_and_netvlad_init_match_reference(name):
+    """only_encoder (kp2dtiny.py:515-518) and NetVLAD.init_params (aggregators/netvlad.py:51-63), reference outputs."""
+    meta, z = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    assert np.max(np.abs(orc.only_encoder(x, sd, cfg) - z["only_encoder"])) < 1e-5
+    alpha, cent, w = orc.netvlad_init_params(z["init_clsts"].copy(), z["init_descs"].copy())
+    assert abs(alpha - float(z["init_alpha"])) < 1e-9 * abs(alpha)
+    assert np.array_equal(w, z["init_conv_weight"]) and np.array_equal(cent, z["init_centroids"])
