@@ -36,6 +36,18 @@
 
 namespace kp2d {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 pair -> (hi, lo) fp16 pairs with hi = rn(x), lo = rn(x - hi): v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16,
+// v_pk_add_f32, v_cvt_pk_f16_f32 (5 instructions per two values)
+__device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
+  const f32x2 v = {x, y};
+  hi = __builtin_convertvector(v, f16x2);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+}
+
 constexpr int IN_ROWS = 18;
 constexpr int IN_PITCH = 24;
 
@@ -57,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give each
   // XCD a contiguous run of tiles: neighbouring tiles (shared halo rows/columns) then hit the same L2.
   int bid = blockIdx.x;
-  if (!(a.dbg & 64)) {
+  if (!KP2D_DBG_ON(64)) {
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any grid size
   }
@@ -101,38 +113,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   // p = g / Q.  Recomputing the divisions by 18 and the 64-bit addresses for every chunk cost ~600 VALU
   // instructions per chunk per thread (KP2D_DBG=15 "skeleton" runs: 1.0 ms of a 4.2 ms forward).
   const int st_q4 = 4 * (tid % Q);
+  // byte offsets from the frame base of each source; OOB marks halo pixels outside the image (and the unused tail
+  // granules): a buffer load at that offset is out of range and returns zeros, which IS the zero padding
+  constexpr int OOB = 0x7ffffff0;
   int st_off0[IN_IT], st_off1[IN_IT], st_lds[IN_IT];
-  unsigned st_ok = 0;
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
     const int g = tid + 256 * it;
     const int p = g / Q;
     const int py = p / IN_ROWS, px = p - py * IN_ROWS;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    if (g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W) st_ok |= 1u << it;
-    st_off0[it] = (int)(gy * a.in0.rs + gx * a.in0.ps) + st_q4;
-    st_off1[it] = (int)(gy * a.in1.rs + gx * a.in1.ps) + st_q4;
+    const bool ok = g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    st_off0[it] = ok ? ((int)(gy * a.in0.rs + gx * a.in0.ps) + st_q4) * 4 : OOB;
+    st_off1[it] = ok ? ((int)(gy * a.in1.rs + gx * a.in1.ps) + st_q4) * 4 : OOB;
     st_lds[it] = (py * IN_PITCH + px) * KCP;
   }
   const int w_lds = (tid / Q) * KCP + 4 * (tid % Q);     // weight granule it lands at w_lds + it * (256 / Q) * KCP
 
+  // Buffer resources: one per source (the frame's slice, so num_records bounds every legal access) and one for this
+  // channel group's packed weights.  MUBUF loads take a 32-bit VGPR offset + an SGPR offset: no 64-bit address
+  // arithmetic and no predication per granule.
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src0), 0, (int)((a.in0.bs - a.in0.o) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src1), 0, (int)((a.in1.bs - a.in1.o) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w + (size_t)blockIdx.y * nchunk * TAPS * N * KC), 0, nchunk * TAPS * N * KC * 4, 0x00020000);
+  // chunks never straddle the two sources and never run past cin when both are multiples of KC (every S config)
+  const bool uniform = ((c0 | a.cin) & (KC - 1)) == 0;
+
   auto prefetch = [&](int ch) {
-    const int c = ch * KC + st_q4;
-    const bool first = c < c0;
-    const float* src = first ? src0 + ch * KC : src1 + (ch * KC - c0);
-    const bool cok = c < a.cin && !(a.dbg & 4);
+    if (KP2D_DBG_ON(4)) {
 #pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cok && ((st_ok >> it) & 1)) v = *reinterpret_cast<const float4*>(src + (first ? st_off0[it] : st_off1[it]));
-      rin[it] = v;
-    }
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + ((size_t)blockIdx.y * nchunk + ch) * TAPS * N * KC);
+      for (int it = 0; it < IN_IT; ++it) rin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int g = tid + 256 * it;
-      rw[it] = ((W_G % 256 == 0 || g < W_G) && !(a.dbg & 4)) ? wsrc[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int it = 0; it < W_IT; ++it) rw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
     }
+    if (uniform) {
+      if (ch * KC < c0) {
+        const int so = ch * KC * 4;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it)
+          rin[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, st_off0[it], so, 0));
+      } else {
+        const int so = (ch * KC - c0) * 4;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it)
+          rin[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, st_off1[it], so, 0));
+      }
+    } else {
+      // per-thread source / tail selection (channel counts that are not multiples of KC: the N configs)
+      const int c = ch * KC + st_q4;
+      const bool first = c < c0;
+      const int so = (first ? ch * KC : ch * KC - c0) * 4;      // per thread: goes into the VGPR offset
+      const bool cok = c < a.cin;
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it) {
+        const int o0 = (cok && first) ? st_off0[it] + so : OOB;
+        const int o1 = (cok && !first) ? st_off1[it] + so : OOB;
+        const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+        const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+        rin[it] = __builtin_bit_cast(float4, v0 | v1);      // the other one is all zeros
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+      rw[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + 256 * it) * 16, 0));
   };
 
   auto commit = [&]() {
@@ -147,15 +194,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
       } else {
         // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; |x| is clamped to the fp16 range
         const float lim = 65000.f;
-        const float x0_ = fminf(fmaxf(v.x, -lim), lim), x1_ = fminf(fmaxf(v.y, -lim), lim);
-        const float x2_ = fminf(fmaxf(v.z, -lim), lim), x3_ = fminf(fmaxf(v.w, -lim), lim);
-        f16x4 hi, lo;
-        hi[0] = (_Float16)x0_; hi[1] = (_Float16)x1_; hi[2] = (_Float16)x2_; hi[3] = (_Float16)x3_;
-        lo[0] = (_Float16)(x0_ - (float)hi[0]); lo[1] = (_Float16)(x1_ - (float)hi[1]);
-        lo[2] = (_Float16)(x2_ - (float)hi[2]); lo[3] = (_Float16)(x3_ - (float)hi[3]);
+        f16x2 h0, h1, l0, l1;
+        split2(__builtin_amdgcn_fmed3f(v.x, -lim, lim), __builtin_amdgcn_fmed3f(v.y, -lim, lim), h0, l0);
+        split2(__builtin_amdgcn_fmed3f(v.z, -lim, lim), __builtin_amdgcn_fmed3f(v.w, -lim, lim), h1, l1);
         _Float16* row = reinterpret_cast<_Float16*>(&s_in[st_lds[it]]);
-        *reinterpret_cast<f16x4*>(row + st_q4) = hi;
-        *reinterpret_cast<f16x4*>(row + 16 + st_q4) = lo;
+        *reinterpret_cast<f16x4*>(row + st_q4) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<f16x4*>(row + 16 + st_q4) = f16x4{l0[0], l0[1], l1[0], l1[1]};
       }
     }
 #pragma unroll
@@ -168,11 +212,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
   prefetch(0);
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();          // every wave is done reading the previous chunk's LDS image
-    if (!(a.dbg & 2)) commit();
+    if (!KP2D_DBG_ON(2)) commit();
     __syncthreads();
     if (ch + 1 < nchunk) prefetch(ch + 1);
 
-    if (!(a.dbg & 8))
+    if (!KP2D_DBG_ON(8))
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 1, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 1;

@@ -3,6 +3,14 @@
 #pragma once
 #include "kp2d_kernels.h"
 
+// Timing ablations (KP2D_DBG bits, DESIGN.md "phase ablations") exist only in a -DKP2D_ABLATE build: as run-time
+// tests they cost a scalar branch per staged granule in the production kernel.
+#ifdef KP2D_ABLATE
+#define KP2D_DBG_ON(bit) ((a.dbg & (bit)) != 0)
+#else
+#define KP2D_DBG_ON(bit) false
+#endif
+
 namespace kp2d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
