@@ -42,6 +42,19 @@ class Kp2dConfig(C.Structure):
     ]
 
 
+class Kp2dLgConfig(C.Structure):
+    """struct kp2d_lg_config (include/kp2d_lightglue.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("input_dim", C.c_int32),
+        ("descriptor_dim", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
 class Kp2dError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"kp2d error {code}: {msg}")
@@ -77,6 +90,15 @@ SIGNATURES = {
     "kp2d_set_chunk_frames": (C.c_int, [_P, C.c_int]),
     "kp2d_set_precision": (C.c_int, [_P, C.c_int]),
     "kp2d_get_precision": (C.c_int, [_P]),
+    # include/kp2d_lightglue.h
+    "kp2d_lg_create": (C.c_int, [C.POINTER(Kp2dLgConfig), C.POINTER(_P)]),
+    "kp2d_lg_destroy": (None, [_P]),
+    "kp2d_lg_num_weights": (C.c_int, [_P]),
+    "kp2d_lg_weight_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), _I64, C.POINTER(C.c_int)]),
+    "kp2d_lg_set_weight": (C.c_int, [_P, C.c_char_p, _P, _I64, C.c_int]),
+    "kp2d_lg_finalize_weights": (C.c_int, [_P]),
+    "kp2d_lg_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    "kp2d_lg_forward": (C.c_int, [_P] + [_P] * 6 + [C.c_int] * 3 + [C.c_float] + [_P] * 7 + [_P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qi = q0 + j;
-  const float* qp = a.q + ((size_t)b * S + (qi < S ? qi : 0)) * C + h * d;
+  const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
+  const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
+  const float* qp = a.q + ((size_t)b * S + (qi < S ? qi : 0)) * qs + h * d;
   float qf[DB][4];
 #pragma unroll
   for (int db = 0; db < DB; ++db)
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
   for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  const float* kvb = a.kv + (size_t)b * T * 2 * C + h * d;
+  const float* kvb = a.kv + (size_t)b * T * kvs + a.k_off + h * d;
 
   for (int kc = 0; kc < T; kc += AKT) {
     __syncthreads();
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
       const int key = kc + skey;
       if (key < T && 4 * squad < d) {
-        const float* p = kvb + (size_t)key * 2 * C + 4 * squad;
+        const float* p = kvb + (size_t)key * kvs + 4 * squad;
         kk = *reinterpret_cast<const float4*>(p);
-        vv = *reinterpret_cast<const float4*>(p + C);
+        vv = *reinterpret_cast<const float4*>(p + vd);
       }
       *reinterpret_cast<float4*>(&Ks[skey * ADP + 4 * squad]) = kk;
       *reinterpret_cast<float4*>(&Vs[skey * ADP + 4 * squad]) = vv;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   l += __shfl_xor(l, 32);
   if (qi < S) {
     const float inv = 1.f / l;
-    float* op = a.out + ((size_t)b * S + qi) * C + h * d;
+    float* op = a.out + ((size_t)b * S + qi) * os + h * d;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll

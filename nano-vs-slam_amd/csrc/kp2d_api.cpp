@@ -972,6 +972,9 @@ size_t plan_bytes_uncached(kp2d_model* m, int Bc, int H, int W) {
 extern "C" {
 
 const char* kp2d_last_error(void) { return g_err.c_str(); }
+extern "C++" {
+namespace kp2d { void set_last_error(const char* msg) { g_err = msg ? msg : ""; } }   // for the other API files
+}
 int32_t kp2d_abi_version(void) { return KP2D_ABI_VERSION; }
 
 int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {

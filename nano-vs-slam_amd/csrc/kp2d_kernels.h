@@ -124,8 +124,49 @@ struct AttnArgs {
   float* out;          // [B][S][C]
   int B, S, T, C, heads;
   float scale;         // (C/heads)^-0.5
+  // row strides / channel offsets in floats; 0 = the dense defaults above (q_stride C, kv_stride 2C, k_off 0,
+  // v_off C, out_stride C).  The LightGlue blocks read q, k, v as slices of one [q|k|v] or [qk|v] row.
+  int q_stride = 0, kv_stride = 0, k_off = 0, v_off = 0, out_stride = 0;
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
+
+void set_last_error(const char* msg);   // thread-local message behind kp2d_last_error() (kp2d_api.cpp)
+
+// ---- LightGlue matcher (lightglue/lightglue.py; kernels in lightglue.hip) -----------------------
+struct LgPosArgs {
+  const float* k0; const float* k1;         // keypoints [B][M][2] / [B][N][2], pixels (x, y)
+  const float* size0; const float* size1;   // image size [B][2] (w, h) or null: 1 + max - min of the keypoints
+  const float* wr;                          // posenc.Wr.weight [hd/2][2]
+  float* cs;                                // [B*M + B*N][hd]: cos(hd/2) | sin(hd/2) per token
+  int B, M, N, hd;
+};
+int launch_lg_posenc(const LgPosArgs& a, hipStream_t s);
+
+enum LgEpi { LG_EPI_NONE = 0, LG_EPI_ROTARY = 1, LG_EPI_LNGELU = 2, LG_EPI_RESID = 3 };
+struct LgLinArgs {
+  const float* x0; const float* x1;         // input = [x0 row (k0 wide) | x1 row (k1 wide)]; x1 unused when k1 == 0
+  int k0, k1, xs0, xs1;                     // widths and row strides (floats)
+  const float* w;                           // W^T packed [K][nout] (nout padded to a multiple of 32)
+  const float* bias;                        // [nout] or null
+  float* out; int os, oo;                   // output row stride / column offset
+  int rows, nout, nvalid;                   // nvalid <= nout columns are stored
+  int epi;
+  const float* cs; int hd, rot_cols;        // ROTARY: per-row cos|sin, head dim, leading columns that rotate
+  const float* ln_g; const float* ln_b;     // LNGELU: LayerNorm affine over the nout columns
+  const float* res; int rs;                 // RESID: out = res + y
+};
+int launch_lg_linear(const LgLinArgs& a, hipStream_t s);
+
+struct LgAssignArgs {
+  const float* fz;                          // [B*M + B*N][fs]: final_proj(x) / D^0.25 in [0,D), matchability logit at D
+  int fs, D, B, M, N;
+  float* scores;                            // [B][M+1][N+1] log assignment (out)
+  float* rlse; float* clse; float* max0;    // scratch [B*M], [B*N], [B*M]
+  int* m0; int* m1;                         // scratch row / column argmax
+  float th;                                 // filter_threshold
+  int64_t* matches0; int64_t* matches1; float* mscores0; float* mscores1;
+};
+int launch_lg_assign(const LgAssignArgs& a, hipStream_t s);
 
 // ---- descriptor matching (src/visual_odometry/feature_matcher.py:89-98, 179-209) ---------------
 struct MatchArgs {

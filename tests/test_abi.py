@@ -16,9 +16,12 @@ def lib_path():
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "kp2d.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(kp2d_[a-z0-9_]+)\s*\(", text)))
+    syms = set()
+    for name in ("kp2d.h", "kp2d_lightglue.h"):
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(kp2d_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_header_and_binding_agree():
@@ -40,6 +43,9 @@ def test_config_struct_layout_matches_header():
     body = text[text.index("typedef struct kp2d_config {"):text.index("} kp2d_config;")]
     names = re.findall(r"int32_t\s+([a-z_0-9]+)", body)
     assert names == [f[0] for f in _lib.Kp2dConfig._fields_]
+    text = open(os.path.join(ROOT, "include", "kp2d_lightglue.h")).read()
+    body = text[text.index("typedef struct kp2d_lg_config {"):text.index("} kp2d_lg_config;")]
+    assert re.findall(r"int32_t\s+([a-z_0-9]+)", body) == [f[0] for f in _lib.Kp2dLgConfig._fields_]
 
 
 def test_create_without_gpu_fails_loudly(lib_path):

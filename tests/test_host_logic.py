@@ -147,3 +147,25 @@ def test_init_netvlad_matches_reference_fixture():
     assert np.array_equal(nv.conv.weight.detach().numpy(), z["init_conv_weight"])
     assert np.array_equal(nv.centroids.detach().numpy(), z["init_centroids"])
     assert [k for k in m.state_dict() if "netvlad" in k] == ["vlad_head.netvlad.centroids", "vlad_head.netvlad.conv.weight"]
+
+
+def test_lightglue_host_mirror_layout_and_no_cpu_path():
+    """LightGlue host mirror: reference import lines, state_dict layout, config table; no CPU execution."""
+    from lightglue.lightglue import LightGlue
+    from lightglue.lightglue_configs import LIGHT_GLUE_CONFIGS, get_light_glue_config
+    from oracle import lightglue_oracle as lgo
+    assert set(LIGHT_GLUE_CONFIGS) == {"S", "F", "A"}
+    with pytest.raises(ValueError):
+        get_light_glue_config("Z")
+    for name in LIGHT_GLUE_CONFIGS:
+        m = LightGlue(get_light_glue_config(name))
+        assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == \
+            list(lgo.state_dict_shapes(lgo.get_config(name)).items())
+    m = LightGlue(get_light_glue_config("S")).eval()
+    assert m.conf.n_layers == 4 and m.conf["filter_threshold"] == 0.0 and m.required_data_keys[0] == "keypoints0"
+    data = {"keypoints0": torch.zeros(1, 8, 2), "keypoints1": torch.zeros(1, 8, 2),
+            "descriptors0": torch.zeros(1, 8, 32), "descriptors1": torch.zeros(1, 8, 32)}
+    with pytest.raises(RuntimeError):
+        m(data)                                      # CPU tensors: refused, never a fallback
+    with pytest.raises(RuntimeError):
+        m.transformers[0].self_attn(torch.zeros(1, 8, 32))

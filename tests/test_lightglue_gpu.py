@@ -1,0 +1,136 @@
+"""HIP LightGlue (include/kp2d_lightglue.h) against the numpy oracle.  The oracle itself is only self-consistent
+(parity unpinned: the reference's lightglue.py cannot be imported here), see oracle/lightglue_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightglue_oracle as lg
+from test_lightglue_oracle import make_data
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def product(conf_in, sd):
+    from lightglue.lightglue import LightGlue
+    m = LightGlue(conf_in)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+def to_dev(data):
+    out = {}
+    for k, v in data.items():
+        out[k] = {"image_size": torch.from_numpy(v["image_size"]).to(DEV)} if isinstance(v, dict) else torch.from_numpy(v).to(DEV)
+    return out
+
+
+def check(pred, ref, conf, th):
+    la, rla = pred["log_assignment"].cpu().numpy(), ref["log_assignment"]
+    assert la.shape == rla.shape
+    assert np.max(np.abs(la - rla) / (1.0 + np.abs(rla))) < 5e-5
+    for k in ("ref_descriptors0", "ref_descriptors1"):
+        assert pred[k].shape == ref[k].shape
+        assert np.max(np.abs(pred[k].cpu().numpy() - ref[k])) < 2e-4 * max(1.0, float(np.abs(ref[k]).max()))
+    # matches: identical wherever the oracle's decision is not within rounding of a tie / of the threshold
+    inner = rla[:, :-1, :-1]
+    top2 = np.sort(inner, axis=2)[:, :, -2:]
+    clear0 = (top2[:, :, 1] - top2[:, :, 0]) > 1e-3
+    m0, rm0 = pred["matches0"].cpu().numpy(), ref["matches0"]
+    s0, rs0 = pred["matching_scores0"].cpu().numpy(), ref["matching_scores0"]
+    near_th = (np.abs(rs0 - th) < 1e-4) & (rs0 > 0)
+    ok = clear0 & ~near_th
+    top2c = np.sort(inner, axis=1)[:, -2:, :]
+    clear1 = (top2c[:, 1] - top2c[:, 0]) > 1e-3
+    # a row's mutual test also depends on its column's argmax being clear
+    ok &= np.take_along_axis(clear1, inner.argmax(2), 1)
+    assert ok.mean() > 0.7          # the mask must leave most rows to compare
+    assert np.array_equal(m0[ok], rm0[ok])
+    assert np.max(np.abs(s0[ok] - rs0[ok])) < 1e-4
+    m1, rm1 = pred["matches1"].cpu().numpy(), ref["matches1"]
+    agree = (m1 == rm1).mean()
+    assert agree > 0.97
+    # consistency of the product's own outputs: matches are mutual and one-to-one
+    for b in range(m0.shape[0]):
+        i = np.nonzero(m0[b] >= 0)[0]
+        assert np.array_equal(m1[b][m0[b][i]], i)
+        assert len(set(m0[b][i].tolist())) == len(i)
+    assert pred["matches0"].dtype == torch.int64 and pred["prune0"].shape == pred["matching_scores0"].shape
+    assert float(pred["prune0"].min()) == conf["n_layers"]
+
+
+@pytest.mark.parametrize("name,B,M,N,th", [("S", 2, 70, 53, 0.1), ("S", 1, 300, 257, 0.0), ("F", 1, 128, 96, 0.1),
+                                           ("A", 3, 17, 64, 0.1)])
+def test_lightglue_matches_oracle(name, B, M, N, th):
+    from lightglue.lightglue_configs import get_light_glue_config
+    conf_in = dict(get_light_glue_config(name), filter_threshold=th)
+    conf = lg.get_config(conf_in)
+    sd = lg.seeded_state_dict(conf)
+    data = make_data(B, M, N, conf["input_dim"], seed=11)
+    ref = lg.forward(data, sd, conf)
+    model = product(conf_in, sd)
+    with torch.no_grad():
+        pred = model(to_dev(data))
+    check(pred, ref, conf, th)
+
+
+def test_lightglue_input_proj_and_keypoint_extent_size():
+    """input_dim != descriptor_dim adds input_proj; image_size None -> 1 + max - min of the keypoints (:140-141)."""
+    conf_in = {"input_dim": 64, "descriptor_dim": 32, "n_layers": 2, "filter_threshold": 0.05}
+    conf = lg.get_config(conf_in)
+    sd = lg.seeded_state_dict(conf)
+    data = make_data(2, 90, 75, 64, seed=5)
+    data["view0"] = {"image_size": None}
+    data["view1"] = {"image_size": None}
+    ref = lg.forward(data, sd, conf)
+    model = product(conf_in, sd)
+    dd = {k: torch.from_numpy(v).to(DEV) for k, v in data.items() if not isinstance(v, dict)}
+    dd["view0"], dd["view1"] = {"image_size": None}, {"image_size": None}
+    with torch.no_grad():
+        pred = model(dd)
+    check(pred, ref, conf, 0.05)
+
+
+def test_lightglue_full_size_properties():
+    """BASELINE config 5 shape (1024 keypoints per image, K3 top-k): swapping the two images transposes the assignment,
+    rows/cols of exp(log_assignment) are sub-stochastic, matches are mutual."""
+    from lightglue.lightglue_configs import get_light_glue_config
+    conf_in = dict(get_light_glue_config("S"), filter_threshold=0.1)
+    conf = lg.get_config(conf_in)
+    sd = lg.seeded_state_dict(conf)
+    data = make_data(2, 1024, 1000, 32, seed=2, size=(640.0, 480.0))
+    model = product(conf_in, sd)
+    d = to_dev(data)
+    sw = {"keypoints0": d["keypoints1"], "keypoints1": d["keypoints0"], "descriptors0": d["descriptors1"],
+          "descriptors1": d["descriptors0"], "view0": d["view1"], "view1": d["view0"]}
+    with torch.no_grad():
+        p, q = model(d), model(sw)
+    la, lb = p["log_assignment"], q["log_assignment"].transpose(1, 2)
+    assert torch.max(torch.abs(la - lb) / (1 + la.abs())) < 5e-5
+    pe = la[:, :-1, :].exp().sum(2)          # each keypoint's assignment mass incl. the dustbin <= ~1
+    assert float(pe.max()) < 1.0 + 1e-3
+    m0, m1 = p["matches0"], p["matches1"]
+    for b in range(2):
+        i = torch.nonzero(m0[b] >= 0)[:, 0]
+        assert torch.equal(m1[b][m0[b][i]], i)
+    assert torch.equal(p["matches0"], q["matches1"]) or (p["matches0"] != q["matches1"]).float().mean() < 0.01
+
+
+def test_lightglue_refuses_unbuilt_modes_and_bad_weights():
+    from lightglue.lightglue import LightGlue
+    from nano_vs_slam_amd import _lib
+    conf = lg.get_config("S")
+    sd = lg.seeded_state_dict(conf)
+    m = product({"input_dim": 32, "descriptor_dim": 32, "n_layers": 4, "depth_confidence": 0.9}, sd)
+    data = to_dev(make_data(1, 20, 20, 32, seed=1))
+    with pytest.raises(NotImplementedError):
+        m(data)
+    with pytest.raises(NotImplementedError):
+        LightGlue({"input_dim": 32, "descriptor_dim": 32, "add_scale_ori": True})
+    big = LightGlue({"input_dim": 256, "descriptor_dim": 256}).to(DEV).eval()      # the upstream default width
+    with pytest.raises(_lib.Kp2dError):
+        big({"keypoints0": torch.zeros(1, 4, 2, device=DEV), "keypoints1": torch.zeros(1, 4, 2, device=DEV),
+             "descriptors0": torch.zeros(1, 4, 256, device=DEV), "descriptors1": torch.zeros(1, 4, 256, device=DEV)})
+    ok = product({"input_dim": 32, "descriptor_dim": 32, "n_layers": 4}, sd)
+    keys = ok.expected_weights()
+    assert keys == list(lg.state_dict_shapes(conf).items())
