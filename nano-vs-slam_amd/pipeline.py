@@ -59,3 +59,27 @@ def inference(net, image, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda
     if single:
         return pts[0], feat[0], out
     return pts, feat, out
+
+
+@torch.no_grad()
+def two_view_match(net, matcher, image0: torch.Tensor, image1: torch.Tensor, max_num_keypoints: int = 1024):
+    """Extractor + LightGlue on batches of image pairs, everything on the device — the model-facing sequence of
+    gluefactory's ``two_view_pipeline`` with the ``kp2dtiny`` extractor and the ``lightglue`` matcher
+    (gluefactory/models/extractors/kp2dtiny.py:24-58, gluefactory/configs/kp2dtiny_S+lightglue_homography.yaml).
+
+    image0 / image1: float32 [B,3,H,W] in [0,1] (the extractor applies ``.sub(0.5).mul(2)`` itself, :25), H and W are
+    cropped to multiples of 8 (:30-33).  Returns (pred0, pred1, matches) with the extractor's and the matcher's dicts.
+    """
+    from .selectors import extract_topk
+    preds = []
+    for img in (image0, image1):
+        H, W = img.shape[-2] - img.shape[-2] % 8, img.shape[-1] - img.shape[-1] % 8
+        x = (img[:, :, :H, :W] - 0.5) * 2.0
+        out = net.post_processing(net(x.contiguous()), H, W)
+        p = extract_topk(out, max_num_keypoints)
+        p["image_size"] = torch.tensor([float(W), float(H)], device=img.device).expand(img.shape[0], 2)
+        preds.append(p)
+    data = {"keypoints0": preds[0]["keypoints"], "keypoints1": preds[1]["keypoints"],
+            "descriptors0": preds[0]["descriptors"], "descriptors1": preds[1]["descriptors"],
+            "view0": {"image_size": preds[0]["image_size"]}, "view1": {"image_size": preds[1]["image_size"]}}
+    return preds[0], preds[1], matcher(data)

@@ -134,3 +134,31 @@ def test_lightglue_refuses_unbuilt_modes_and_bad_weights():
     ok = product({"input_dim": 32, "descriptor_dim": 32, "n_layers": 4}, sd)
     keys = ok.expected_weights()
     assert keys == list(lg.state_dict_shapes(conf).items())
+
+
+def test_two_view_pipeline_extractor_plus_matcher():
+    """gluefactory-style two-view sequence: extractor -> K3 top-k -> LightGlue, all on the device; matching an image
+    against itself must pair (almost) every keypoint with itself."""
+    from lightglue.lightglue import LightGlue
+    from lightglue.lightglue_configs import get_light_glue_config
+    from nano_vs_slam_amd.pipeline import two_view_match
+    from conftest import product_model
+    net, _ = product_model("S", False, 28)
+    conf = dict(get_light_glue_config("S"), filter_threshold=0.0)
+    sd = lg.seeded_state_dict(lg.get_config(conf))
+    matcher = product(conf, sd)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    img = torch.rand(2, 3, 125, 163, device=DEV, generator=g)          # cropped to 120 x 160 by the extractor
+    p0, p1, m = two_view_match(net, matcher, img, img, max_num_keypoints=256)
+    assert p0["keypoints"].shape == (2, 256, 2) and p0["descriptors"].shape == (2, 256, 32)
+    assert torch.equal(p0["keypoints"], p1["keypoints"])
+    assert m["log_assignment"].shape == (2, 257, 257)
+    ar = torch.arange(256, device=DEV)[None].expand(2, -1)
+    matched = m["matches0"] >= 0
+    assert torch.equal(m["matches0"][matched], ar[matched])            # a keypoint can only match itself
+    ref = lg.forward({"keypoints0": p0["keypoints"].cpu().numpy(), "keypoints1": p1["keypoints"].cpu().numpy(),
+                      "descriptors0": p0["descriptors"].cpu().numpy(), "descriptors1": p1["descriptors"].cpu().numpy(),
+                      "view0": {"image_size": np.array([[160.0, 120.0]] * 2, np.float32)},
+                      "view1": {"image_size": np.array([[160.0, 120.0]] * 2, np.float32)}}, sd, lg.get_config(conf))
+    la, rla = m["log_assignment"].cpu().numpy(), ref["log_assignment"]
+    assert np.max(np.abs(la - rla) / (1.0 + np.abs(rla))) < 5e-5

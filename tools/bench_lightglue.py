@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: KP2DTiny-S keypoints + LightGlue on 480x640 image pairs (synthetic frames, seeded weights).
+
+    python3 tools/bench_lightglue.py [--pairs 8] [--steps 20] [--kpts 1024]
+
+Prints one JSON line: image pairs/s for extractor (both images) + K3 top-k + matcher, and the matcher alone.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kpts", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    a = ap.parse_args()
+    from lightglue.lightglue import LightGlue
+    from lightglue.lightglue_configs import get_light_glue_config
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from nano_vs_slam_amd.pipeline import two_view_match
+    from oracle import lightglue_oracle as lgo
+    from oracle.weights import spread_state_dict
+    dev = torch.device("cuda:0")
+    net = tiny_factory("S", 28)
+    sd = spread_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net = net.to(dev).eval()
+    net.training = False
+    conf = dict(get_light_glue_config("S"), filter_threshold=0.1)
+    lg = LightGlue(conf)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in lgo.seeded_state_dict(lgo.get_config(conf)).items()})
+    lg = lg.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    im0 = torch.rand(a.pairs, 3, a.height, a.width, device=dev, generator=g)
+    im1 = torch.rand(a.pairs, 3, a.height, a.width, device=dev, generator=g)
+
+    def timed(fn):
+        for _ in range(a.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / a.steps * 1e3
+
+    with torch.no_grad():
+        p0, p1, m = two_view_match(net, lg, im0, im1, a.kpts)
+        data = {"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"], "descriptors0": p0["descriptors"],
+                "descriptors1": p1["descriptors"], "view0": {"image_size": p0["image_size"]},
+                "view1": {"image_size": p1["image_size"]}}
+        t_all = timed(lambda: two_view_match(net, lg, im0, im1, a.kpts))
+        t_lg = timed(lambda: lg(data))
+    print(json.dumps({
+        "metric": "image pairs/sec KP2DTiny-S + LightGlue 480x640", "value": round(a.pairs / t_all * 1e3, 1),
+        "unit": "pairs/s", "pairs_per_step": a.pairs, "keypoints": a.kpts, "ms_per_step": round(t_all, 3),
+        "matcher_ms_per_step": round(t_lg, 3), "matcher_pairs_per_s": round(a.pairs / t_lg * 1e3, 1),
+        "matched_fraction": round(float((m["matches0"] >= 0).float().mean()), 4), "data": "synthetic",
+        "dtype": "f16x3 extractor, fp32 matcher"}))
+
+
+if __name__ == "__main__":
+    main()
