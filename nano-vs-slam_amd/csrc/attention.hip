@@ -212,9 +212,173 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split-fp16 streaming attention (prec 1, head dim d <= 16): the same "x = hi + lo, three MFMAs into one fp32
+// accumulator" arithmetic as the convolutions (conv3x3.hip), on v_mfma_f32_32x32x16_f16 — 3.5x fewer matrix-core
+// cycles than the fp32 16x16x4 kernel above, which is what a 19200-query x 4800-key frame (480x640) is bound by.
+//   grid (ceil(S/128), heads, B); wave = 32 queries.  Per 32-key tile:
+//   S^T[key][query] = K_tile (32 x 16) . Q^T (16 x 32)                      one MFMA triple, K = d
+//   O^T[chan][query] += V^T (16 x 32 keys) . P^T (32 keys x 32 queries)     two MFMA triples (K = 16 keys each)
+//   A lane holds 16 keys of ONE query column of S^T, so the online softmax is register-local plus one xor-32 step,
+//   and P^T in that layout is the B operand of the second product once V^T is staged with the matching key order:
+//   accumulator register r = 8t + j of lane-half h is key 16t + 8(j>>2) + 4h + (j&3) -> slot (t, h, j).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void att_split2(float x, float y, h16x2& hi, h16x2& lo) {
+  const f32x2_ v = {x, y};
+  hi = __builtin_convertvector(v, h16x2);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2_), h16x2);
+}
+__device__ __forceinline__ void att_split8(const float (&x)[8], h16x8& hi, h16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    h16x2 h, l;
+    att_split2(x[j], x[j + 1], h, l);
+    hi[j] = h[0]; hi[j + 1] = h[1]; lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
+
+constexpr int SKT = 128;   // keys per LDS chunk (four 32-key tiles)
+constexpr int SKP = 40;    // K row pitch in halves: 16 hi | 16 lo | 8 pad  (80 B)
+constexpr int SVP = 40;    // V^T row pitch in halves: 32 keys | 8 pad
+
+__global__ __launch_bounds__(256) void attention_split_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
+  __shared__ __attribute__((aligned(16))) _Float16 Vt[(SKT / 32) * 16 * 2 * SVP];   // [tile][chan][hi|lo][SVP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
+  const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
+  const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
+  const int qi = blockIdx.x * 128 + wave * 32 + i;
+  // Q^T operand: lane (query i, h) holds channels 8h..8h+7, pre-multiplied by scale * log2(e) so that the
+  // softmax runs on exp2 directly
+  h16x8 qh, ql;
+  {
+    const float* qp = a.q + ((size_t)b * S + (qi < S ? qi : 0)) * qs + hd * d;
+    const float f = a.scale * 1.44269504088896340736f;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (qi < S && 8 * h + j < d) ? qp[8 * h + j] * f : 0.f;
+    att_split8(x, qh, ql);
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float* kvb = a.kv + (size_t)b * T * kvs + a.k_off + hd * d;
+
+  for (int kc = 0; kc < T; kc += SKT) {
+    __syncthreads();
+    // stage: granule e = (key, 4 channels).  K row-major split rows; V transposed with the slot permutation.
+    for (int e = tid; e < SKT * 4; e += 256) {
+      const int key = e >> 2, q4 = e & 3;
+      float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+      if (kc + key < T && 4 * q4 < d) {
+        const float* p = kvb + (size_t)(kc + key) * kvs + 4 * q4;
+        kk = *reinterpret_cast<const float4*>(p);
+        vv = *reinterpret_cast<const float4*>(p + vd);
+      }
+      h16x2 h0, h1, l0, l1;
+      att_split2(kk.x, kk.y, h0, l0);
+      att_split2(kk.z, kk.w, h1, l1);
+      *reinterpret_cast<h16x4*>(&Ks[key * SKP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<h16x4*>(&Ks[key * SKP + 16 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
+      att_split2(vv.x, vv.y, h0, l0);
+      att_split2(vv.z, vv.w, h1, l1);
+      const int tile = key >> 5, kk32 = key & 31, rem = kk32 & 15;
+      const int pos = (kk32 >> 4) * 16 + ((rem >> 2) & 1) * 8 + (((rem >> 3) << 2) | (rem & 3));
+      _Float16* vt = &Vt[((tile * 16 + 4 * q4) * 2) * SVP + pos];
+      vt[0] = h0[0]; vt[SVP] = l0[0];
+      vt[2 * SVP] = h0[1]; vt[3 * SVP] = l0[1];
+      vt[4 * SVP] = h1[0]; vt[5 * SVP] = l1[0];
+      vt[6 * SVP] = h1[1]; vt[7 * SVP] = l1[1];
+    }
+    __syncthreads();
+    const int ntile = min(SKT, T - kc + 31) >> 5;
+    for (int t32 = 0; t32 < (SKT >> 5); ++t32) {
+      if (t32 >= ntile) break;
+      // S^T tile: rows = keys 32*t32 + i
+      const h16x8 kh = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 8 * h]);
+      const h16x8 kl = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 16 + 8 * h]);
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sc, 0, 0, 0);
+      const int kbase = kc + t32 * 32 + 4 * h;
+      if (kc + t32 * 32 + 32 > T) {             // only the last tile of the sequence has keys past T (uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) >= T) sc[r] = -INFINITY;
+      }
+      float mx = m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (__any(mx != m)) {                     // running maxima moved for some query of this wave: rescale
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);       // first tile: exp2(-inf) = 0
+        m = mx;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] *= alpha;          // rows >= 16 of O^T are padding and stay zero
+      }
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mx); l += p[r]; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        h16x8 ph, pl;
+        const float (&pp)[8] = *reinterpret_cast<const float (*)[8]>(&p[8 * t]);
+        att_split8(pp, ph, pl);
+        h16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { vh[j] = (_Float16)0; vl[j] = (_Float16)0; }
+        if (i < 16) {
+          const _Float16* vt = &Vt[((t32 * 16 + i) * 2) * SVP + t * 16 + 8 * h];
+          vh = *reinterpret_cast<const h16x8*>(vt);
+          vl = *reinterpret_cast<const h16x8*>(vt + SVP);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+      }
+    }
+  }
+  l += __shfl_xor(l, 32);
+  if (qi < S) {
+    const float inv = 1.f / l;
+    float* op = a.out + ((size_t)b * S + qi) * os + hd * d;
+    // accumulator register r < 8 of lane-half h: channel (r & 3) + 8 (r >> 2) + 4h
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c0 = 8 * g + 4 * h;
+      if (c0 + 3 < d) {
+        *reinterpret_cast<float4*>(op + c0) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r < d) op[c0 + r] = o[4 * g + r] * inv;
+      }
+    }
+  }
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t s) {
   const int d = a.C / a.heads;
   if (a.C % a.heads || d > 64 || (d & 3) || (a.C & 3)) return -1402;
+  if (a.prec == 1 && d <= 16) {
+    hipLaunchKernelGGL(attention_split_kernel, dim3((a.S + 127) / 128, a.heads, a.B), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+  }
   const dim3 grid((a.S + 63) / 64, a.heads, a.B);
   if (d <= 16) hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, a);
   else if (d <= 32) hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, s, a);

@@ -658,6 +658,7 @@ struct Plan {
     if (rc == KP2D_OK && !dry) {
       const int heads = 4;
       AttnArgs a{ptr(q), ptr(kv), ptr(ao), B, h * w, (h / 2) * (w / 2), C, heads, 1.0f / std::sqrt((float)(C / heads))};
+      a.prec = m->precision == KP2D_PREC_F16X3 ? 1 : 0;
       const double st = (double)B * h * w * (h / 2) * (w / 2);
       prof_begin(p + ".att.fn", "attention", 4.0 * st * C, 4.0 * B * ((double)2 * h * w * C + (h / 2) * (w / 2) * 2.0 * C));
       check(launch_attention(a, stream), (p + ".att.fn").c_str());

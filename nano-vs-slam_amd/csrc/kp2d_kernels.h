@@ -127,6 +127,7 @@ struct AttnArgs {
   // row strides / channel offsets in floats; 0 = the dense defaults above (q_stride C, kv_stride 2C, k_off 0,
   // v_off C, out_stride C).  The LightGlue blocks read q, k, v as slices of one [q|k|v] or [qk|v] row.
   int q_stride = 0, kv_stride = 0, k_off = 0, v_off = 0, out_stride = 0;
+  int prec = 0;        // 1: split-fp16 operands on v_mfma_f32_32x32x16_f16 (head dim <= 16), 0: exact fp32 MFMA
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
