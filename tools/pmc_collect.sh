@@ -6,6 +6,9 @@ set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# one stream lane: every conv launch then covers the whole 64-frame batch, the same launch shape bench.py's
+# HIP-event roofline figures are taken on (profiling mode runs single-lane); per-launch bytes are comparable
+export KP2D_LANES=1
 run() {  # name, counters...
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o "$name" -- \
