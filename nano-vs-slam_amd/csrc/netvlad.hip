@@ -11,6 +11,8 @@
 //   pass 2: grid (B); sums the partials in split order, subtracts rowsum * centroid, does both
 //           normalisations with wavefront shuffles + one LDS exchange.
 // The input is the NHWC output of vlad_head.convlad3, so a pixel's C channels are one contiguous line.
+#include <cstdlib>
+
 #include "kp2d_kernels.h"
 
 namespace kp2d {
@@ -18,7 +20,8 @@ namespace kp2d {
 constexpr int VT = 64;  // pixels per LDS tile
 
 int netvlad_nsplit(int S) {
-  int n = (S + 319) / 320;  // ~5 tiles of 64 pixels per workgroup
+  static const int per = getenv("KP2D_VLAD_PX") ? atoi(getenv("KP2D_VLAD_PX")) : 320;   // pixels per workgroup (tuning knob)
+  int n = (S + per - 1) / per;
   return n < 1 ? 1 : n;
 }
 
