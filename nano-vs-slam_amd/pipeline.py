@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .selectors import select_keypoints
+from .selectors import select_keypoints, select_keypoints_host
 
 
 def frames_to_input(frames, device, size=None) -> torch.Tensor:
@@ -52,9 +52,9 @@ def inference(net, image, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda
     scale = None
     if new_size is not None and (H, W) != src_hw:     # pts / scale: visual_odometry.py:81-83, 119-121
         scale = (W / float(src_hw[1]), H / float(src_hw[0]))
-    sel = select_keypoints(out, nn_thresh, top_k, scale)
-    pts = [p.cpu().numpy().copy() for p, _, _ in sel]
-    feat = [d.cpu().numpy().copy() for _, d, _ in sel]
+    sel = select_keypoints_host(out, nn_thresh, top_k, scale)
+    pts = [p for p, _ in sel]
+    feat = [d for _, d in sel]
     single = (not torch.is_tensor(image) and np.asarray(image).ndim == 3) or (torch.is_tensor(image) and image.dim() == 3)
     if single:
         return pts[0], feat[0], out

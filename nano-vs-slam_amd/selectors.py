@@ -75,6 +75,21 @@ def select_keypoints(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, scale
     return res
 
 
+def select_keypoints_host(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, scale=None):
+    """K1/K2 delivered to the host as the reference's ``inference()`` returns them: per frame (pts [n,2], desc [n,C])
+    numpy arrays.  Three device-to-host copies for the whole batch (counts, padded points, padded descriptors) instead
+    of two per frame."""
+    score, coord, feat = out["score"], out["coord"], out["feat"]
+    idx, _val, cnt = select_topk(score, top_k, nn_thresh)
+    pts, dsel = gather_keypoints(coord, feat, idx)
+    if scale is not None:
+        pts = pts / torch.tensor([scale[0], scale[1]], device=pts.device, dtype=pts.dtype)
+    counts = cnt.tolist()
+    kmax = max(counts) if counts else 0
+    hp, hd = pts[:, :kmax].cpu().numpy(), dsel[:, :kmax].cpu().numpy()
+    return [(hp[b, :n].copy(), hd[b, :n].copy()) for b, n in enumerate(counts)]
+
+
 def extract_topk(out: dict, max_num_keypoints: int = 1024):
     """K3: batched top-k without threshold -> dict like the gluefactory extractor's ``pred``."""
     idx, val, _ = select_topk(out["score"], max_num_keypoints)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the frame front-end: uint8 HWC frames in HOST memory -> device -> kp2d_preprocess -> forward
+-> post_processing -> threshold/top-k selection -> selected rows back to the host (pipeline.inference).  Not the
+headline metric (bench.py starts with inputs resident in HBM); DESIGN.md §5 quotes this number beside it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--pinned", action="store_true")
+    a = ap.parse_args()
+    from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
+    from nano_vs_slam_amd.pipeline import inference
+    from oracle.weights import spread_state_dict
+    net = tiny_factory("S", 28)
+    sd = spread_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net = net.to("cuda:0").eval()
+    net.training = False
+    frames = np.random.default_rng(0).integers(0, 256, (a.batch, 240, 320, 3), dtype=np.uint8)
+    src = torch.from_numpy(frames).pin_memory() if a.pinned else frames
+    for _ in range(3):
+        inference(net, src, None, 0.7, 1000, "cuda:0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        inference(net, src, None, 0.7, 1000, "cuda:0")
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. H2D of uint8 frames and D2H of keypoints",
+                      "value": round(a.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "batch": a.batch,
+                      "host_memory": "pinned" if a.pinned else "pageable"}))
+
+
+if __name__ == "__main__":
+    main()
