@@ -5,6 +5,7 @@ keypoint index sets identical.  Two faithful fp32 implementations differ by ~2e-
 ``reference_vs_fp64``), so the float asserts below use 2e-4 — 5x tighter than the contract — and index
 sets are compared exactly except for cells closer than 2e-5 to a decision boundary.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -434,3 +435,40 @@ def test_remove_netvlad_wins_over_pooler():
     ref = orc.forward(x, sd, cfg)
     assert out["vlad"].shape == ref["vlad"].shape == (1, 48, 8, 12)
     assert np.max(np.abs(out["vlad"].cpu().numpy() - ref["vlad"])) < TOL
+
+
+def test_vo_frontend_wrapper_matches_reference_contract():
+    """KP2DtinyFrontend.run (src/visual_odometry/frontend.py:78-129): threshold, optional semantic filter, top-k; the
+    reference's import line resolves to the device-side implementation."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "src"))
+    from visual_odometry.frontend import KP2DtinyFrontend
+    from oracle.weights import spread_state_dict
+    H, W = 120, 160
+    fe = KP2DtinyFrontend((H, W), None, nn_thresh=0.7, device=DEV, debug=False, config="S", top_k=50, nClasses=28)
+    sd = spread_state_dict({k: tuple(v.shape) for k, v in fe.net.state_dict().items()})
+    fe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    x = synthetic_frames(1, H, W, seed=8)
+    img = torch.from_numpy((x[0] + 1.0) / 2.0)                    # the wrapper applies .sub(0.5).mul(2) itself
+    pts, feat, seg = fe.run(img)
+    cfg = orc.get_config("S")
+    ref = orc.post_processing(orc.forward(x, sd, cfg), H, W, cfg)
+    idx, rpts, rdesc = orc.select_k1(ref["score"], ref["coord"], ref["feat"], 0.7, 50)
+    assert pts.shape == (len(idx), 2) and feat.shape == (len(idx), 32) and seg.shape == (60 * 80,)
+    order = np.lexsort((pts[:, 1], pts[:, 0]))
+    rorder = np.lexsort((rpts[:, 1], rpts[:, 0]))
+    assert np.max(np.abs(pts[order] - rpts[rorder])) < 5e-4 and np.max(np.abs(feat[order] - rdesc[rorder])) < TOL
+    info = fe.get_info()
+    assert info["top_k"] == 50 and info["model"]["total_params"] > 0
+    # semantic filter: cells whose sampled class is listed never come back
+    fe2 = KP2DtinyFrontend((H, W), None, nn_thresh=0.7, device=DEV, semantic_filter=True, classes_to_filter=[3, 7, 11],
+                           debug=False, config="S", top_k=4000, nClasses=28)
+    fe2.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    pts2, feat2, seg2 = fe2.run(img)
+    with torch.no_grad():
+        out = fe2.net.post_processing(fe2.net(torch.from_numpy(x).to(DEV)), H, W)
+    sc, cls = out["score"].view(-1).cpu().numpy(), out["seg"].view(-1).cpu().numpy()
+    keep = (sc > 0.7) & ~np.isin(cls, [3, 7, 11])
+    assert len(pts2) == keep.sum() == len(seg2) and not np.isin(seg2, [3, 7, 11]).any()
+    assert sorted(seg2.tolist()) == sorted(cls[keep].tolist())
+    assert keep.sum() < (sc > 0.7).sum()                           # the filter removed something
