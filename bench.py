@@ -231,6 +231,10 @@ def main():
                 "share_of_kernel_time": round(a["ms"] / total_ms, 4),
                 "algorithmic_gb_per_s": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1),
                 "kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 3) for k, v in agg.items()}}
+        if split:
+            # a bare fp16 MFMA loop sustains 1571 TFLOP/s on this chip (clock drops to ~1.5 GHz under matrix load:
+            # tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log) -> 523.7 TFLOP/s of fp32-grade products
+            roof["frac_of_sustained_mfma"] = round(achieved / (1571.0 / 3.0), 4)
         # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_collect.sh): bench.py
         # cannot run rocprofv3 around itself, so the per-launch figure measured on this workload is read back
         try:
