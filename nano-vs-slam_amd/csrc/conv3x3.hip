@@ -34,6 +34,10 @@
 //           3 MFMAs of 16x the fp32 rate -> 5.3x fewer matrix-core cycles per product.
 #include "conv_common.h"
 
+#ifndef KP2D_PITCH_NT1
+#define KP2D_PITCH_NT1 20
+#endif
+
 namespace kp2d {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -49,11 +53,14 @@ __device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
 }
 
 constexpr int IN_ROWS = 18;
-constexpr int IN_PITCH = 24;
+// LDS row pitch of the input image in pixels.  32-channel tiles (NT = 1) use 20 so that image + weight slab is
+// 51.8 KB and THREE workgroups fit a CU (160 registers per thread allow it); the 64-channel tiles use 24.
+template <int NT> struct InPitch { static constexpr int v = NT == 1 ? KP2D_PITCH_NT1 : 24; };
 
 template <int KC, int NT, int TAPS, int PREC>
-__global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void conv3x3_f32_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int IN_PITCH = InPitch<NT>::v;
   constexpr int KCP = KC + 4;
   constexpr int N = NT * 32;
   constexpr int Q = KC / 4;
@@ -281,6 +288,7 @@ template <int KC, int NT, int TAPS, int PREC>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
   static_assert(PREC == 0 || KC == 16, "split-fp16 mode walks K in chunks of 16 (one 32x32x16 MFMA)");
   constexpr int KCP = KC + 4;
+  constexpr int IN_PITCH = InPitch<NT>::v;
   size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + TAPS * NT * 32 * KCP) * sizeof(float);
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
