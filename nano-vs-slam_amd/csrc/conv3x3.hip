@@ -32,6 +32,8 @@
 //           relative, so the result is fp32-grade: measured max error vs fp64 1.7e-6 at K = 576 against
 //           1.9e-6 for the exact fp32 chain (tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log).
 //           3 MFMAs of 16x the fp32 rate -> 5.3x fewer matrix-core cycles per product.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 #ifndef KP2D_PITCH_NT1
@@ -55,12 +57,17 @@ __device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
 constexpr int IN_ROWS = 18;
 // LDS row pitch of the input image in pixels.  32-channel tiles (NT = 1) use 20 so that image + weight slab is
 // 51.8 KB and THREE workgroups fit a CU (160 registers per thread allow it); the 64-channel tiles use 24.
-template <int NT> struct InPitch { static constexpr int v = NT == 1 ? KP2D_PITCH_NT1 : 24; };
+template <int NT, int WST> struct InPitch { static constexpr int v = (NT == 1 || WST > 1) ? KP2D_PITCH_NT1 : 24; };
 
-template <int KC, int NT, int TAPS, int PREC>
-__global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void conv3x3_f32_kernel(const ConvArgs a) {
+// WST = weight stages per K chunk.  1: all taps of the chunk's weight slab sit in LDS at once.  3 (64-channel tiles):
+// one tap row (3 taps) at a time, restaged between MFMA segments: 28.8 + 15.4 KB of LDS instead of 80.6 KB and a
+// 12-register weight prefetch instead of 36, which is what lets THREE of these workgroups share a CU.
+template <int KC, int NT, int TAPS, int PREC, int WST = 1>
+__global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) ? 3 : 2) void conv3x3_f32_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int IN_PITCH = InPitch<NT>::v;
+  constexpr int IN_PITCH = InPitch<NT, WST>::v;
+  static_assert(TAPS % WST == 0, "weight stages must divide the taps");
+  constexpr int STAPS = TAPS / WST;       // taps per weight stage
   constexpr int KCP = KC + 4;
   constexpr int N = NT * 32;
   constexpr int Q = KC / 4;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
   // L2/HBM latency hides under the matrix-core work of this wave and of the co-resident workgroup.
   constexpr int IN_G = IN_ROWS * IN_ROWS * Q;
   constexpr int IN_IT = (IN_G + 255) / 256;
-  constexpr int W_G = TAPS * N * Q;
+  constexpr int W_G = STAPS * N * Q;      // weight granules per stage
   constexpr int W_IT = (W_G + 255) / 256;
   float4 rin[IN_IT], rw[W_IT];
 
@@ -149,12 +156,17 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
   // chunks never straddle the two sources and never run past cin when both are multiples of KC (every S config)
   const bool uniform = ((c0 | a.cin) & (KC - 1)) == 0;
 
-  auto prefetch = [&](int ch) {
+  auto prefetch_w = [&](int ch, int stage) {
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+      rw[it] = KP2D_DBG_ON(4) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                              : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rsw, tid * 16, ((ch * WST + stage) * W_G + 256 * it) * 16, 0));
+  };
+  auto prefetch_in = [&](int ch) {
     if (KP2D_DBG_ON(4)) {
 #pragma unroll
       for (int it = 0; it < IN_IT; ++it) rin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int it = 0; it < W_IT; ++it) rw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       return;
     }
     if (uniform) {
@@ -184,12 +196,9 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
         rin[it] = __builtin_bit_cast(float4, v0 | v1);      // the other one is all zeros
       }
     }
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it)
-      rw[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + 256 * it) * 16, 0));
   };
 
-  auto commit = [&]() {
+  auto commit_in = [&]() {
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
       if (IN_G % 256 != 0 && tid + 256 * it >= IN_G) continue;
@@ -209,6 +218,8 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
         *reinterpret_cast<f16x4*>(row + 16 + st_q4) = f16x4{l0[0], l0[1], l1[0], l1[1]};
       }
     }
+  };
+  auto commit_w = [&]() {
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
       if (W_G % 256 != 0 && tid + 256 * it >= W_G) continue;
@@ -216,16 +227,25 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
     }
   };
 
-  prefetch(0);
+  prefetch_in(0);
+  prefetch_w(0, 0);
   for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();          // every wave is done reading the previous chunk's LDS image
-    if (!KP2D_DBG_ON(2)) commit();
+#pragma unroll
+   for (int stage = 0; stage < WST; ++stage) {
+    __syncthreads();          // every wave is done reading the previous stage's LDS image
+    if (!KP2D_DBG_ON(2)) {
+      if (stage == 0) commit_in();
+      commit_w();
+    }
     __syncthreads();
-    if (ch + 1 < nchunk) prefetch(ch + 1);
+    // next loads: the following weight stage of this chunk, or the next chunk's input tile + first weight stage
+    if (stage + 1 < WST) prefetch_w(ch, stage + 1);
+    else if (ch + 1 < nchunk) { prefetch_in(ch + 1); prefetch_w(ch + 1, 0); }
 
     if (!KP2D_DBG_ON(8))
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int tl = 0; tl < STAPS; ++tl) {
+      const int tap = stage * STAPS + tl;      // tap in the 3x3 window; tl indexes the staged slab
       const int dy = TAPS == 9 ? tap / 3 : 1, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 1;
       if (PREC == 0) {
         float av[2][KH], bv[NT][KH];
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const float* p = &s_w[b_base + (tap * N + n * 32) * KCP];
+          const float* p = &s_w[b_base + (tl * N + n * 32) * KCP];
 #pragma unroll
           for (int j = 0; j < KH; j += 4) {
             const float4 t = *reinterpret_cast<const float4*>(p + j);
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const float* p = &s_w[b_base16 + (tap * N + n * 32) * KCP];
+          const float* p = &s_w[b_base16 + (tl * N + n * 32) * KCP];
           bh[n] = *reinterpret_cast<const f16x8*>(p);
           bl[n] = *reinterpret_cast<const f16x8*>(p + 8);
         }
@@ -279,24 +299,27 @@ __global__ __launch_bounds__(256, (NT == 1 && KP2D_PITCH_NT1 < 24) ? 3 : 2) void
           }
       }
     }
+   }
   }
 
+  constexpr int EPI_ROUNDS = (WST > 1 && NT == 2) ? 2 : 1;
 #include "conv_epilogue.inc"
 }
 
-template <int KC, int NT, int TAPS, int PREC>
+template <int KC, int NT, int TAPS, int PREC, int WST = 1>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
   static_assert(PREC == 0 || KC == 16, "split-fp16 mode walks K in chunks of 16 (one 32x32x16 MFMA)");
   constexpr int KCP = KC + 4;
-  constexpr int IN_PITCH = InPitch<NT>::v;
-  size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + TAPS * NT * 32 * KCP) * sizeof(float);
+  constexpr int IN_PITCH = InPitch<NT, WST>::v;
+  size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + (TAPS / WST) * NT * 32 * KCP) * sizeof(float);
   const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
-  const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float);   // [pixel][N] staging of the fp32 NHWC epilogue
+  // [pixel][N] staging tile of the fp32 NHWC epilogue; half the pixel rows per round for the weight-staged 64-channel tile
+  const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float) / ((WST > 1 && NT == 2) ? 2 : 1);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC, WST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
@@ -304,7 +327,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
-  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS, PREC>), dim3(grid, groups), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f32_kernel<KC, NT, TAPS, PREC, WST>), dim3(grid, groups), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -314,7 +337,8 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   const bool one = a.npad == 32;
   if (a.prec == 1) {
     if (kc != 16) return -1003;
-    if (a.taps == 9) return one ? launch_t<16, 1, 9, 1>(a, s) : launch_t<16, 2, 9, 1>(a, s);
+    static const bool wst3 = !(getenv("KP2D_WST") && getenv("KP2D_WST")[0] == '1');
+    if (a.taps == 9) return one ? launch_t<16, 1, 9, 1>(a, s) : (wst3 ? launch_t<16, 2, 9, 1, 3>(a, s) : launch_t<16, 2, 9, 1>(a, s));
     if (a.taps == 1) return one ? launch_t<16, 1, 1, 1>(a, s) : launch_t<16, 2, 1, 1>(a, s);
     return -1000;
   }
