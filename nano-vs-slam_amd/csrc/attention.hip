@@ -248,7 +248,7 @@ constexpr int SKT = 128;   // keys per LDS chunk (four 32-key tiles)
 constexpr int SKP = 40;    // K row pitch in halves: 16 hi | 16 lo | 8 pad  (80 B)
 constexpr int SVP = 40;    // V^T row pitch in halves: 32 keys | 8 pad
 
-__global__ __launch_bounds__(256) void attention_split_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
   __shared__ __attribute__((aligned(16))) _Float16 Vt[(SKT / 32) * 16 * 2 * SVP];   // [tile][chan][hi|lo][SVP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
