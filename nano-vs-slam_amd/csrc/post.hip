@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
   unsigned& s_rank = hist[256];
   unsigned& s_ncand = hist[257];
   unsigned& s_fill = hist[258];
+  unsigned& s_done = hist[259];
 
   if (tid == 0) s_ncand = 0;
   __syncthreads();
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
 
   unsigned long long thresh = ~0ull;   // nothing selected
   if (count > 0) {
-    if (tid == 0) { s_prefix = 0ull; s_rank = count; }
+    if (tid == 0) { s_prefix = 0ull; s_rank = count; s_done = 0u; }
     __syncthreads();
     for (int pass = 7; pass >= 0; --pass) {
       hist[tid] = 0;
@@ -192,17 +193,34 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
         if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned rank = s_rank, cum = 0;
-        int bin = 255;
-        for (; bin > 0; --bin) {
-          if (cum + hist[bin] >= rank) break;
-          cum += hist[bin];
+      if (tid < 64) {
+        // wave 0 locates the bin holding the rank-th largest key: lane l owns bins 4l..4l+3, a suffix sum over lanes
+        // gives the number of keys in higher bins (the serial 256-step scan this replaces was ~10 % of the kernel)
+        const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const unsigned mine = h0 + h1 + h2 + h3;
+        unsigned above = mine;                       // inclusive suffix sum over lanes >= tid
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned v = __shfl_down(above, o);
+          if (tid + o < 64) above += v;
         }
-        s_rank = rank - cum;
-        s_prefix = prefix | ((unsigned long long)bin << shift);
+        above -= mine;                               // keys in bins of higher lanes
+        const unsigned rank = s_rank;
+        if (above < rank && rank <= above + mine) {  // exactly one lane: the rank-th key is in one of its 4 bins
+          unsigned cum = above;
+          int bin = 4 * tid + 3;
+          unsigned hb = h3;
+          if (cum + h3 < rank) { cum += h3; bin = 4 * tid + 2; hb = h2;
+            if (cum + h2 < rank) { cum += h2; bin = 4 * tid + 1; hb = h1;
+              if (cum + h1 < rank) { cum += h1; bin = 4 * tid; hb = h0; } } }
+          s_rank = rank - cum;
+          s_prefix = prefix | ((unsigned long long)bin << shift);
+          // every key of the chosen bin is selected: the remaining digits cannot change the set (keys are unique,
+          // so this is reached at the latest when the bin holds one key) -> stop refining
+          s_done = (rank - cum == hb) ? 1u : 0u;
+        }
       }
       __syncthreads();
+      if (s_done) break;
     }
     thresh = s_prefix;   // the count-th largest key
   }
