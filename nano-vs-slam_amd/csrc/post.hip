@@ -104,6 +104,28 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(const ArgmaxArgs a) {
   a.ids[(size_t)b * a.HW + p] = (int64_t)bi;
 }
 
+// four consecutive pixels per thread (HW % 4 == 0): 16-byte loads per class plane, two 16-byte stores of ids
+__global__ __launch_bounds__(256) void seg_argmax4_kernel(const ArgmaxArgs a) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;       // quad of pixels
+  const int b = blockIdx.y;
+  if (q * 4 >= (size_t)a.HW) return;
+  const float4* sp = reinterpret_cast<const float4*>(a.seg + (size_t)b * a.C * a.HW) + q;
+  const size_t plane4 = (size_t)a.HW >> 2;
+  float4 best = sp[0];
+  int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll 4
+  for (int c = 1; c < a.C; ++c) {
+    const float4 v = sp[(size_t)c * plane4];
+    if (v.x > best.x) { best.x = v.x; b0 = c; }   // first maximum wins, as torch.argmax on CPU
+    if (v.y > best.y) { best.y = v.y; b1 = c; }
+    if (v.z > best.z) { best.z = v.z; b2 = c; }
+    if (v.w > best.w) { best.w = v.w; b3 = c; }
+  }
+  longlong2* o = reinterpret_cast<longlong2*>(a.ids + (size_t)b * a.HW + q * 4);
+  o[0] = make_longlong2(b0, b1);
+  o[1] = make_longlong2(b2, b3);
+}
+
 // sample_seg with sample_segmentation=True (models/kp2dtiny.py:634-639): nearest-neighbour grid_sample of the
 // class map at every cell's predicted coordinate (align_corners=True, zeros outside), then argmax.
 __global__ __launch_bounds__(256) void seg_sample_argmax_kernel(const SegSampleArgs a) {
@@ -134,7 +156,10 @@ int launch_seg_sample_argmax(const SegSampleArgs& a, hipStream_t s) {
 }
 
 int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(seg_argmax_kernel, dim3((a.HW + 255) / 256, a.B), dim3(256), 0, s, a);
+  if ((a.HW & 3) == 0 && ((uintptr_t)a.seg & 15) == 0 && ((uintptr_t)a.ids & 15) == 0)
+    hipLaunchKernelGGL(seg_argmax4_kernel, dim3((a.HW / 4 + 255) / 256, a.B), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(seg_argmax_kernel, dim3((a.HW + 255) / 256, a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
