@@ -14,18 +14,29 @@
 
 namespace kp2d {
 
+// Workgroup = 64 cells x 4 channel quarters: wave w samples channels [w*C/4, (w+1)*C/4) of the same 64 cells (each
+// wave-load still walks one feature plane), the squared norms meet in LDS.  8 gathers x 4 corners per thread instead
+// of 32 x 4 keeps four times as many loads in flight per cell.
 template <int C>
 __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
+  __shared__ float s_ss[4][64];
+  constexpr int CW = C / 4;
   const int Hc = a.Hc, Wc = a.Wc;
   const int ncell = Hc * Wc;
-  const int cell_id = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int cell_id = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (cell_id >= ncell) return;
+  const bool live = cell_id < ncell;
+  if (!live) {                       // keep the barrier below uniform
+    s_ss[part][lane] = 0.f;
+    __syncthreads();
+    return;
+  }
   const int yc = cell_id / Wc, xc = cell_id - yc * Wc;
   const size_t so = (size_t)b * ncell + cell_id;
 
   const bool border = (yc == 0) | (yc == Hc - 1) | (xc == 0) | (xc == Wc - 1);
-  a.score_out[so] = __fmul_rn(a.score_in[so], border ? 0.f : 1.f);
+  if (part == 0) a.score_out[so] = __fmul_rn(a.score_in[so], border ? 0.f : 1.f);
 
   const float step = (float)(a.cell - 1) * 0.5f;
   const float gain = a.cross_ratio * step;
@@ -35,9 +46,11 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   float cy = __fadd_rn(__fadd_rn(__fmul_rn((float)yc, (float)a.cell), step), __fmul_rn(sy, gain));
   cx = fminf(fmaxf(cx, 0.f), (float)(a.W - 1));
   cy = fminf(fmaxf(cy, 0.f), (float)(a.H - 1));
-  a.coord[((size_t)b * 2 + 0) * ncell + cell_id] = cx;
-  a.coord[((size_t)b * 2 + 1) * ncell + cell_id] = cy;
-  if (a.desc == nullptr) return;
+  if (part == 0) {
+    a.coord[((size_t)b * 2 + 0) * ncell + cell_id] = cx;
+    a.coord[((size_t)b * 2 + 1) * ncell + cell_id] = cy;
+  }
+  if (a.desc == nullptr) return;      // uniform: no barrier is reached on this path
 
   // normalize_coord with the IMAGE size, then grid_sample's un-normalisation with the FEATURE size
   const float gx = __fsub_rn(__fdiv_rn(cx, (float)(a.W - 1) * 0.5f), 1.f);
@@ -58,13 +71,13 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   const int cx0 = min(max(x0, 0), Wf - 1), cx1 = min(max(x1, 0), Wf - 1);
   const int cy0 = min(max(y0, 0), Hf - 1), cy1 = min(max(y1, 0), Hf - 1);
   const size_t plane = (size_t)Hf * Wf;
-  const float* f = a.feat + (size_t)b * C * plane;
+  const float* f = a.feat + ((size_t)b * C + (size_t)part * CW) * plane;
   const size_t o00 = (size_t)cy0 * Wf + cx0, o01 = (size_t)cy0 * Wf + cx1;
   const size_t o10 = (size_t)cy1 * Wf + cx0, o11 = (size_t)cy1 * Wf + cx1;
-  float d[C];
+  float d[CW];
   float ss = 0.f;
-#pragma unroll 8
-  for (int c = 0; c < C; ++c) {
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
     const float* fp = f + c * plane;
     float v = __fmul_rn(fp[o00], w00);
     v = __fadd_rn(v, __fmul_rn(fp[o01], w01));
@@ -73,14 +86,17 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
     d[c] = v;
     ss = fmaf(v, v, ss);
   }
-  const float nrm = sqrtf(ss);   // no eps: models/kp2dtiny.py:629-630
-#pragma unroll 8
-  for (int c = 0; c < C; ++c) a.desc[((size_t)b * C + c) * ncell + cell_id] = __fdiv_rn(d[c], nrm);
+  s_ss[part][lane] = ss;
+  __syncthreads();
+  // channel-ascending summation order of the quarter sums (the per-quarter sums are themselves channel-ascending)
+  const float nrm = sqrtf(((s_ss[0][lane] + s_ss[1][lane]) + s_ss[2][lane]) + s_ss[3][lane]);   // no eps: kp2dtiny.py:629-630
+#pragma unroll
+  for (int c = 0; c < CW; ++c) a.desc[((size_t)b * C + part * CW + c) * ncell + cell_id] = __fdiv_rn(d[c], nrm);
 }
 
 int launch_post(const PostArgs& a, hipStream_t s) {
   const int ncell = a.Hc * a.Wc;
-  dim3 grid((ncell + 255) / 256, a.B);
+  dim3 grid((ncell + 63) / 64, a.B);
   switch (a.C) {
     case 32: hipLaunchKernelGGL(post_kernel<32>, grid, dim3(256), 0, s, a); break;
     case 64: hipLaunchKernelGGL(post_kernel<64>, grid, dim3(256), 0, s, a); break;
