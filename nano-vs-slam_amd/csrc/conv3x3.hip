@@ -342,8 +342,9 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
     if (a.taps == 1) return one ? launch_t<16, 1, 1, 1>(a, s) : launch_t<16, 2, 1, 1>(a, s);
     return -1000;
   }
+  static const bool wst3f = !(getenv("KP2D_WST") && getenv("KP2D_WST")[0] == '1');
   if (a.taps == 9) {
-    if (kc == 16) return one ? launch_t<16, 1, 9, 0>(a, s) : launch_t<16, 2, 9, 0>(a, s);
+    if (kc == 16) return one ? launch_t<16, 1, 9, 0>(a, s) : (wst3f ? launch_t<16, 2, 9, 0, 3>(a, s) : launch_t<16, 2, 9, 0>(a, s));
     if (kc == 8) return one ? launch_t<8, 1, 9, 0>(a, s) : launch_t<8, 2, 9, 0>(a, s);
   } else if (a.taps == 1) {
     if (kc == 16) return one ? launch_t<16, 1, 1, 0>(a, s) : launch_t<16, 2, 1, 0>(a, s);
