@@ -472,3 +472,32 @@ def test_vo_frontend_wrapper_matches_reference_contract():
     assert len(pts2) == keep.sum() == len(seg2) and not np.isin(seg2, [3, 7, 11]).any()
     assert sorted(seg2.tolist()) == sorted(cls[keep].tolist())
     assert keep.sum() < (sc > 0.7).sum()                           # the filter removed something
+
+
+def test_streams_views_and_coexisting_models():
+    """The engine enqueues on the caller's current stream, accepts non-contiguous inputs, and two models (handles) can
+    interleave calls; results do not depend on any of it."""
+    m1, sd1 = product_model("S", False, 28)
+    m2, sd2 = product_model("N", True, 19)
+    x = synthetic_frames(3, 48, 64, seed=13)
+    xt = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        ref1 = {k: v.clone() for k, v in m1(xt).items()}
+        ref2 = {k: v.clone() for k, v in m2(xt).items()}
+        # non-contiguous view (channels-last memory) and a side stream, the two models interleaved
+        xv = xt.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        assert not xv.is_contiguous()
+        side = torch.cuda.Stream(device=DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            a1 = m1(xv)
+            a2 = m2(xv)
+            b1 = m1.post_processing(dict(a1), 48, 64)
+        side.synchronize()
+        p1 = m1.post_processing(dict(ref1), 48, 64)
+    for k in ref1:
+        assert torch.equal(a1[k], ref1[k]), k
+    for k in ref2:
+        assert torch.equal(a2[k], ref2[k]), k
+    for k in ("score", "coord", "feat", "seg"):
+        assert torch.equal(b1[k], p1[k]), k
