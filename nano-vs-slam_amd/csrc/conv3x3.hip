@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
   }
 
   constexpr int EPI_ROUNDS = (WST > 1 && NT == 2) ? 2 : 1;
+  constexpr bool EPI_GELU = TAPS == 1;
 #include "conv_epilogue.inc"
 }
 

@@ -32,6 +32,21 @@ __device__ __attribute__((noinline)) float act_apply(float v, int act, int ch) {
   }
 }
 
+// Exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. a
+// GELU error below |x| * 1e-7): 15 instructions inline, against ~60 plus a call for libm's erff through act_apply —
+// the MixFFN's GELU layer spent more time in its epilogue than in its matrix product.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 // "S16" activation format (f16x3 mode): a pixel's channels in blocks of 16, each block 64 B =
 // [16 x fp16 hi][16 x fp16 lo] with hi = fp16(x), lo = fp16(x - hi) — the operand form the split-fp16 MFMA
 // consumes, written once by the producer instead of being re-derived by every consumer workgroup.

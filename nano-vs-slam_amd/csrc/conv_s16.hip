@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const ConvArgs a) {
     }
   }
   constexpr int EPI_ROUNDS = 1;
+  constexpr bool EPI_GELU = false;
 #include "conv_epilogue.inc"
 }
 
