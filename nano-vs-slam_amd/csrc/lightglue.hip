@@ -1,13 +1,13 @@
 // LightGlue matcher kernels (reference: lightglue/lightglue.py; inference path, flash = False, no early stopping /
 // point pruning).  Descriptor width D <= 64 (configs S / A: 32, F: 64), 4 heads, <= 1024 keypoints per image: the
-// whole matcher is ~2 GFLOP per image pair and launch/latency bound, so everything is exact fp32 and the kernels are
-// row-wise: both images' tokens live in ONE row-major buffer [B*M rows of image 0 | B*N rows of image 1] so that every
+// whole matcher is ~2 GFLOP per image pair and launch/latency bound, so the token-wise layers are plain fp32 FMAs (the
+// attention products use the fp32-grade split-fp16 MFMA kernel of attention.hip) and the kernels are row-wise: both images' tokens live in ONE row-major buffer [B*M rows of image 0 | B*N rows of image 1] so that every
 // per-token layer (Linear, rotary, LayerNorm, GELU, residual) is a single launch over all tokens of the batch.
 //
 //  lg_posenc_kernel     normalize_keypoints (:137-149) + LearnableFourierPositionalEncoding (:168-173)
 //  lg_linear_kernel     Y = X W^T + b with fused epilogues: rotary on the q|k columns (:158-159, :253-257),
 //                       LayerNorm + GELU (ffn.1, ffn.2), residual add (x + ffn(...), :261)
-//  (attention)          attention.hip: softmax(q k^T / sqrt(d)) v, streaming, fp32 matrix cores (:208-224, :312-321)
+//  (attention)          attention.hip: softmax(q k^T / sqrt(d)) v, streaming, split-fp16 matrix cores (:208-224, :312-321)
 //  lg_sim_kernel        sim = f0 f1^T (:391)
 //  lg_rowlse / lg_col   row / column log-sum-exp of sim, column argmax of the final scores
 //  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + row max/argmax (filter_matches :403-404)
@@ -271,7 +271,23 @@ __global__ __launch_bounds__(256) void lg_col_kernel(const LgAssignArgs a) {
   float m = -INFINITY, s = 0.f;
   int arg = 0;
   if (j < N) {
-    for (int i = sl; i < M; i += 4) {
+    // four rows in flight per thread: the column walk is a chain of dependent, latency-bound loads otherwise
+    int i = sl;
+    for (; i + 12 < M; i += 16) {
+      const float v0 = sc[(size_t)i * (N + 1) + j], v1 = sc[(size_t)(i + 4) * (N + 1) + j];
+      const float v2 = sc[(size_t)(i + 8) * (N + 1) + j], v3 = sc[(size_t)(i + 12) * (N + 1) + j];
+      if (MODE == 0) {
+        const float mm = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), m);
+        s = s * expf(m - mm) + expf(v0 - mm) + expf(v1 - mm) + expf(v2 - mm) + expf(v3 - mm);
+        m = mm;
+      } else {
+        if (v0 > m) { m = v0; arg = i; }
+        if (v1 > m) { m = v1; arg = i + 4; }
+        if (v2 > m) { m = v2; arg = i + 8; }
+        if (v3 > m) { m = v3; arg = i + 12; }
+      }
+    }
+    for (; i < M; i += 4) {
       const float v = sc[(size_t)i * (N + 1) + j];
       if (MODE == 0) lse_merge(m, s, v, 1.f);
       else if (v > m) { m = v; arg = i; }

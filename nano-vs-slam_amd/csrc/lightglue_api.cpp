@@ -323,6 +323,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         const int n = set ? N : M;
         AttnArgs t{T3 + r0 * 3 * d, T3 + r0 * 3 * d, CTX + r0 * d, B, n, n, d, heads, scale};
         t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d;
+        t.prec = 1;      // split-fp16 MFMA (fp32-grade, attention.hip): 3x faster than the fp32 16x16x4 kernel at head dim 8
         LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
       }
       a = linear(L.out_proj, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
@@ -338,6 +339,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         const size_t rq = set ? (size_t)R0 : 0, rk = set ? 0 : (size_t)R0;
         AttnArgs t{T3 + rq * 2 * d, T3 + rk * 2 * d, CTX + rq * d, B, set ? N : M, set ? M : N, d, heads, scale};
         t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d;
+        t.prec = 1;
         LG_CHECK(launch_attention(t, st), "cross_attn");
       }
       a = linear(L.to_out, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
