@@ -71,13 +71,19 @@ def two_view_match(net, matcher, image0: torch.Tensor, image1: torch.Tensor, max
     cropped to multiples of 8 (:30-33).  Returns (pred0, pred1, matches) with the extractor's and the matcher's dicts.
     """
     from .selectors import extract_topk
+    if image0.shape != image1.shape:
+        raise ValueError("two_view_match expects both views at the same size")
+    B = image0.shape[0]
+    H, W = image0.shape[-2] - image0.shape[-2] % 8, image0.shape[-1] - image0.shape[-1] % 8
+    # both views go through the extractor as ONE batch (frames are independent): twice the work per launch
+    x = (torch.cat([image0[:, :, :H, :W], image1[:, :, :H, :W]], 0) - 0.5) * 2.0
+    out = net.post_processing(net(x.contiguous()), H, W)
+    both = extract_topk(out, max_num_keypoints)
+    size = torch.tensor([float(W), float(H)], device=x.device).expand(B, 2)
     preds = []
-    for img in (image0, image1):
-        H, W = img.shape[-2] - img.shape[-2] % 8, img.shape[-1] - img.shape[-1] % 8
-        x = (img[:, :, :H, :W] - 0.5) * 2.0
-        out = net.post_processing(net(x.contiguous()), H, W)
-        p = extract_topk(out, max_num_keypoints)
-        p["image_size"] = torch.tensor([float(W), float(H)], device=img.device).expand(img.shape[0], 2)
+    for v in range(2):
+        p = {k: t[v * B:(v + 1) * B] for k, t in both.items()}
+        p["image_size"] = size
         preds.append(p)
     data = {"keypoints0": preds[0]["keypoints"], "keypoints1": preds[1]["keypoints"],
             "descriptors0": preds[0]["descriptors"], "descriptors1": preds[1]["descriptors"],
