@@ -24,19 +24,15 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   const int Hc = a.Hc, Wc = a.Wc;
   const int ncell = Hc * Wc;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int cell_id = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  const bool live = cell_id < ncell;
-  if (!live) {                       // keep the barrier below uniform
-    s_ss[part][lane] = 0.f;
-    __syncthreads();
-    return;
-  }
+  // lanes past the last cell of a partial block recompute the last cell and store nothing: one control path, one barrier
+  const bool live = blockIdx.x * 64 + lane < ncell;
+  const int cell_id = live ? blockIdx.x * 64 + lane : ncell - 1;
   const int yc = cell_id / Wc, xc = cell_id - yc * Wc;
   const size_t so = (size_t)b * ncell + cell_id;
 
   const bool border = (yc == 0) | (yc == Hc - 1) | (xc == 0) | (xc == Wc - 1);
-  if (part == 0) a.score_out[so] = __fmul_rn(a.score_in[so], border ? 0.f : 1.f);
+  if (part == 0 && live) a.score_out[so] = __fmul_rn(a.score_in[so], border ? 0.f : 1.f);
 
   const float step = (float)(a.cell - 1) * 0.5f;
   const float gain = a.cross_ratio * step;
@@ -46,7 +42,7 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   float cy = __fadd_rn(__fadd_rn(__fmul_rn((float)yc, (float)a.cell), step), __fmul_rn(sy, gain));
   cx = fminf(fmaxf(cx, 0.f), (float)(a.W - 1));
   cy = fminf(fmaxf(cy, 0.f), (float)(a.H - 1));
-  if (part == 0) {
+  if (part == 0 && live) {
     a.coord[((size_t)b * 2 + 0) * ncell + cell_id] = cx;
     a.coord[((size_t)b * 2 + 1) * ncell + cell_id] = cy;
   }
@@ -90,8 +86,10 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   __syncthreads();
   // channel-ascending summation order of the quarter sums (the per-quarter sums are themselves channel-ascending)
   const float nrm = sqrtf(((s_ss[0][lane] + s_ss[1][lane]) + s_ss[2][lane]) + s_ss[3][lane]);   // no eps: kp2dtiny.py:629-630
+  if (live) {
 #pragma unroll
-  for (int c = 0; c < CW; ++c) a.desc[((size_t)b * C + part * CW + c) * ncell + cell_id] = __fdiv_rn(d[c], nrm);
+    for (int c = 0; c < CW; ++c) a.desc[((size_t)b * C + part * CW + c) * ncell + cell_id] = __fdiv_rn(d[c], nrm);
+  }
 }
 
 int launch_post(const PostArgs& a, hipStream_t s) {
