@@ -78,13 +78,18 @@ __global__ __launch_bounds__(256) void lg_linear_kernel(const LgLinArgs a) {
   float* wt = sm + (size_t)K * LG_ROWS; // [K][nout]
   const int tid = threadIdx.x, rg = tid >> 4, cg = tid & 15;
   const int row0 = blockIdx.x * LG_ROWS;
-  for (int e = tid; e < K * nout; e += 256) wt[e] = a.w[e];
-  for (int e = tid; e < LG_ROWS * K; e += 256) {
-    const int r = e / K, k = e - r * K;
+  // staging with 16-byte loads (nout % 32 == 0; the launcher checks k0, k1 and the row strides are multiples of 4)
+  for (int e = tid; e < (K * nout) >> 2; e += 256)
+    reinterpret_cast<float4*>(wt)[e] = reinterpret_cast<const float4*>(a.w)[e];
+  const int K4 = K >> 2;
+  for (int e = tid; e < LG_ROWS * K4; e += 256) {
+    const int r = e / K4, k = 4 * (e - r * K4);
     const int row = row0 + r;
-    float v = 0.f;
-    if (row < a.rows) v = k < a.k0 ? a.x0[(size_t)row * a.xs0 + k] : a.x1[(size_t)row * a.xs1 + (k - a.k0)];
-    xt[k * LG_ROWS + r] = v;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.rows)
+      v = k < a.k0 ? *reinterpret_cast<const float4*>(a.x0 + (size_t)row * a.xs0 + k)
+                   : *reinterpret_cast<const float4*>(a.x1 + (size_t)row * a.xs1 + (k - a.k0));
+    xt[k * LG_ROWS + r] = v.x; xt[(k + 1) * LG_ROWS + r] = v.y; xt[(k + 2) * LG_ROWS + r] = v.z; xt[(k + 3) * LG_ROWS + r] = v.w;
   }
   __syncthreads();
   float acc[4][2 * LG_NJ];
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) void lg_linear_kernel(const LgLinArgs a) {
 
 int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
   const int K = a.k0 + a.k1;
-  if (a.nout < 32 || (a.nout & 31) || a.nout > 32 * LG_NJ || K < 1 || K > 128) return -1801;
+  if (a.nout < 32 || (a.nout & 31) || a.nout > 32 * LG_NJ || K < 4 || K > 128) return -1801;
+  if ((a.k0 & 3) || (a.k1 & 3) || (a.xs0 & 3) || (a.k1 && (a.xs1 & 3))) return -1801;     // 16-byte staging loads
   if (a.epi == LG_EPI_ROTARY && ((a.hd & 1) || (a.rot_cols & 1) || !a.cs)) return -1802;
   const size_t lds = (size_t)K * (LG_ROWS + a.nout) * sizeof(float);
   static bool attr_done = false;
