@@ -58,7 +58,7 @@ def parse():
 
 
 def seeded_state_dict(model):
-    from oracle.weights import spread_state_dict
+    from nano_vs_slam_amd.synthetic import spread_state_dict
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     return spread_state_dict(shapes)
 

@@ -27,7 +27,7 @@ def main():
     if os.path.exists(a.weights):
         model.load_state_dict(torch.load(a.weights, map_location=torch.device("cpu"))["state_dict"], strict=False)
     else:
-        from oracle.weights import spread_state_dict   # seeded stand-in weights (test infrastructure)
+        from nano_vs_slam_amd.synthetic import spread_state_dict   # seeded stand-in weights (test infrastructure)
         sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
         print(f"{a.weights} not found: using seeded synthetic weights")

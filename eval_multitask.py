@@ -77,7 +77,7 @@ def main(args):
             print("strict load failed, loading non-strict")
             model.load_state_dict(sd, strict=False)
     else:
-        from oracle.weights import spread_state_dict   # seeded stand-in weights (test infrastructure)
+        from nano_vs_slam_amd.synthetic import spread_state_dict   # seeded stand-in weights (test infrastructure)
         sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         print("no --model_path: using seeded synthetic weights")

@@ -71,23 +71,9 @@ def state_dict_shapes(conf: dict) -> dict:
 
 
 def seeded_state_dict(conf: dict, seed: int = 4321) -> dict:
-    """Spread weights for parity work: Linear ~ N(0, 1/fan_in) * gain, LayerNorm gamma ~ U(0.5,1.5), small biases.
-    Keyed by name (crc32) like oracle/weights.py so the enumeration order does not matter."""
-    import zlib
-    out = {}
-    for k, shp in state_dict_shapes(conf).items():
-        g = np.random.default_rng([seed, zlib.crc32(k.encode())])
-        if k.endswith(".1.weight"):
-            v = g.uniform(0.5, 1.5, shp)
-        elif k.endswith("bias"):
-            v = g.standard_normal(shp) * 0.1
-        elif k == "posenc.Wr.weight":
-            v = g.standard_normal(shp) * 2.0          # a few radians across the normalised image
-        else:
-            gain = 2.0 if ("Wqkv" in k or "to_qk" in k or "final_proj" in k) else 1.0
-            v = g.standard_normal(shp) * gain / math.sqrt(shp[-1])
-        out[k] = v.astype(np.float32)
-    return out
+    """Seeded spread weights for parity work (generator shared with the tools: nano-vs-slam_amd/synthetic.py)."""
+    from oracle.weights import seeded_linear_state_dict
+    return seeded_linear_state_dict(state_dict_shapes(conf), seed)
 
 
 # --------------------------------------------------------------------------

@@ -22,7 +22,7 @@ def main():
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import inference
-    from oracle.weights import spread_state_dict
+    from nano_vs_slam_amd.synthetic import spread_state_dict
     net = tiny_factory("S", 28)
     sd = spread_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})

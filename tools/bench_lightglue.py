@@ -30,8 +30,8 @@ def main():
     from lightglue.lightglue_configs import get_light_glue_config
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import two_view_match
-    from oracle import lightglue_oracle as lgo
-    from oracle.weights import spread_state_dict
+    from nano_vs_slam_amd.synthetic import seeded_linear_state_dict
+    from nano_vs_slam_amd.synthetic import spread_state_dict
     dev = torch.device("cuda:0")
     net = tiny_factory("S", 28)
     sd = spread_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
@@ -40,7 +40,8 @@ def main():
     net.training = False
     conf = dict(get_light_glue_config("S"), filter_threshold=0.1)
     lg = LightGlue(conf)
-    lg.load_state_dict({k: torch.from_numpy(v) for k, v in lgo.seeded_state_dict(lgo.get_config(conf)).items()})
+    shapes = {k: tuple(v.shape) for k, v in lg.state_dict().items()}
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_linear_state_dict(shapes).items()})
     lg = lg.to(dev).eval()
     g = torch.Generator(device=dev).manual_seed(0)
     im0 = torch.rand(a.pairs, 3, a.height, a.width, device=dev, generator=g)

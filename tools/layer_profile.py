@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
-    from oracle.weights import spread_state_dict
+    from nano_vs_slam_amd.synthetic import spread_state_dict
     model = tiny_factory(a.config, a.n_classes, v3=a.v3)
     sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
