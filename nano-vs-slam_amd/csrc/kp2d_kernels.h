@@ -158,6 +158,17 @@ struct LgLinArgs {
 };
 int launch_lg_linear(const LgLinArgs& a, hipStream_t s);
 
+// fused tail of a Self/CrossBlock for D = 32: x += ffn(cat[x, out_proj(ctx)])  (lightglue.py:260-261 / :322-326)
+struct LgTailArgs {
+  float* x; const float* ctx;           // [rows][D] in place / attention context
+  const float* wo; const float* bo;      // out_proj / to_out: W^T [D][D], bias
+  const float* w1; const float* b1;      // ffn.0: W^T [2D][2D], bias
+  const float* ln_g; const float* ln_b;  // ffn.1
+  const float* w2; const float* b2;      // ffn.3: W^T [2D][D], bias
+  int rows, D;
+};
+int launch_lg_tail(const LgTailArgs& a, hipStream_t s);
+
 struct LgAssignArgs {
   const float* fz;                          // [B*M + B*N][fs]: final_proj(x) / D^0.25 in [0,D), matchability logit at D
   int fs, D, B, M, N;

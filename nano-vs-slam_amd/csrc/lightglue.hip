@@ -208,6 +208,133 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused block tail for D = 32: message = out_proj(ctx); h = GELU(LayerNorm(W1 [x | message] + b1)); x += W2 h + b2.
+// All three products are row-local, so one workgroup carries its 64 rows through them with the intermediate tiles
+// (transposed, [k][row]) in LDS: 3 launches and 2 HBM round trips of the message / hidden tensors less per block.
+// Same thread mapping as lg_linear_kernel (thread = 4 rows x column pairs {2cg + 32j, +1}).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
+  constexpr int D = 32, D2 = 64, R = LG_ROWS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wo = sm;                  // [D][D]
+  float* w1 = wo + D * D;          // [D2][D2]
+  float* w2 = w1 + D2 * D2;        // [D2][D]
+  float* ct = w2 + D2 * D;         // [D][R]   ctx^T
+  float* xt = ct + D * R;          // [D2][R]  (x | message)^T, later h^T
+  const int tid = threadIdx.x, rg = tid >> 4, cg = tid & 15;
+  const int row0 = blockIdx.x * R;
+  for (int e = tid; e < (D * D) >> 2; e += 256) reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(a.wo)[e];
+  for (int e = tid; e < (D2 * D2) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.w1)[e];
+  for (int e = tid; e < (D2 * D) >> 2; e += 256) reinterpret_cast<float4*>(w2)[e] = reinterpret_cast<const float4*>(a.w2)[e];
+  for (int e = tid; e < R * (D >> 2); e += 256) {
+    const int r = e >> 3, k = 4 * (e & 7);
+    const int row = row0 + r;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), x = c;
+    if (row < a.rows) {
+      c = *reinterpret_cast<const float4*>(a.ctx + (size_t)row * D + k);
+      x = *reinterpret_cast<const float4*>(a.x + (size_t)row * D + k);
+    }
+    ct[k * R + r] = c.x; ct[(k + 1) * R + r] = c.y; ct[(k + 2) * R + r] = c.z; ct[(k + 3) * R + r] = c.w;
+    xt[k * R + r] = x.x; xt[(k + 1) * R + r] = x.y; xt[(k + 2) * R + r] = x.z; xt[(k + 3) * R + r] = x.w;
+  }
+  __syncthreads();
+  // ---- stage 1: message[64 x 32] = ctx Wo^T + bo -> xt rows D..2D ----
+  {
+    float acc[4][2] = {};
+    for (int k = 0; k < D; ++k) {
+      const float4 xv = *reinterpret_cast<const float4*>(&ct[k * R + 4 * rg]);
+      const float2 wv = *reinterpret_cast<const float2*>(&wo[k * D + 2 * cg]);
+      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
+    }
+    const float b0 = a.bo[2 * cg], b1 = a.bo[2 * cg + 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xt[(D + 2 * cg) * R + 4 * rg + r] = acc[r][0] + b0;
+      xt[(D + 2 * cg + 1) * R + 4 * rg + r] = acc[r][1] + b1;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: h[64 x 64] = GELU(LayerNorm([x | message] W1^T + b1)) ----
+  float h[4][4];
+  {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) h[r][c] = 0.f;
+    for (int k = 0; k < D2; ++k) {
+      const float4 xv = *reinterpret_cast<const float4*>(&xt[k * R + 4 * rg]);
+      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float2 wv = *reinterpret_cast<const float2*>(&w1[k * D2 + 2 * cg + 32 * j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r][2 * j] = fmaf(xr[r], wv.x, h[r][2 * j]); h[r][2 * j + 1] = fmaf(xr[r], wv.y, h[r][2 * j + 1]); }
+      }
+    }
+    float bb[4], gg[4], be[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 2 * cg + 32 * (c >> 1) + (c & 1);
+      bb[c] = a.b1[col]; gg[c] = a.ln_g[col]; be[c] = a.ln_b[col];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { h[r][c] += bb[c]; s += h[r][c]; }
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+      const float mu = s * (1.f / D2);
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float d = h[r][c] - mu; q = fmaf(d, d, q); }
+      for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+      const float rs = 1.f / sqrtf(q * (1.f / D2) + 1e-5f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float y = (h[r][c] - mu) * rs * gg[c] + be[c];
+        h[r][c] = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+      }
+    }
+  }
+  __syncthreads();                 // every thread is done reading (x | message)^T
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + 4 * rg + r] = h[r][c];
+  __syncthreads();
+  // ---- stage 3: x += h W2^T + b2 ----
+  {
+    float acc[4][2] = {};
+    for (int k = 0; k < D2; ++k) {
+      const float4 xv = *reinterpret_cast<const float4*>(&xt[k * R + 4 * rg]);
+      const float2 wv = *reinterpret_cast<const float2*>(&w2[k * D + 2 * cg]);
+      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
+    }
+    const float b0 = a.b2[2 * cg], b1 = a.b2[2 * cg + 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * rg + r;
+      if (row < a.rows) {
+        float2* xp = reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg);
+        const float2 old = *xp;
+        *xp = make_float2(old.x + acc[r][0] + b0, old.y + acc[r][1] + b1);
+      }
+    }
+  }
+}
+
+int launch_lg_tail(const LgTailArgs& a, hipStream_t s) {
+  if (a.D != 32) return -1804;
+  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + 32 * LG_ROWS + 64 * LG_ROWS) * sizeof(float);
+  hipLaunchKernelGGL(lg_tail_kernel, dim3((a.rows + LG_ROWS - 1) / LG_ROWS), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Assignment.  scores is the reference's [B][M+1][N+1] log-assignment tensor; its inner block first holds sim.
 // ---------------------------------------------------------------------------------------------
 // sim tile 64 x 64 per workgroup; thread (ty = tid/16, tx = tid%16) owns a 4 x 4 block

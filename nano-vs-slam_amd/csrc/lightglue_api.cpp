@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -310,6 +311,15 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     LG_CHECK(launch_lg_linear(a, st), what);
     return KP2D_OK;
   };
+  // D = 32 (configs S, A): out_proj / to_out + ffn + residual as ONE row-local kernel (lightglue.hip lg_tail_kernel)
+  static const bool fuse_tail = !(getenv("KP2D_LG_FUSE") && getenv("KP2D_LG_FUSE")[0] == '0');
+  auto tail = [&](const Lin& proj, const Ffn& f, const char* what) -> int {
+    LgTailArgs t{};
+    t.x = X; t.ctx = CTX; t.wo = blob + proj.w; t.bo = blob + proj.b; t.w1 = blob + f.l0.w; t.b1 = blob + f.l0.b;
+    t.ln_g = blob + f.g; t.ln_b = blob + f.be; t.w2 = blob + f.l3.w; t.b2 = blob + f.l3.b; t.rows = R; t.D = d;
+    LG_CHECK(launch_lg_tail(t, st), what);
+    return KP2D_OK;
+  };
   const float scale = 1.f / std::sqrt((float)hd);
   for (int i = 0; i < m->cfg.n_layers; ++i) {
     const Layer& L = m->layers[i];
@@ -326,10 +336,15 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         t.prec = 1;      // split-fp16 MFMA (fp32-grade, attention.hip): 3x faster than the fp32 16x16x4 kernel at head dim 8
         LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
       }
-      a = linear(L.out_proj, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
-      LG_CHECK(launch_lg_linear(a, st), "self_attn.out_proj");
-      int rc = ffn(L.fs, "self_attn.ffn");
-      if (rc != KP2D_OK) return rc;
+      if (fuse_tail && d == 32) {
+        int rc = tail(L.out_proj, L.fs, "self_attn tail");
+        if (rc != KP2D_OK) return rc;
+      } else {
+        a = linear(L.out_proj, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
+        LG_CHECK(launch_lg_linear(a, st), "self_attn.out_proj");
+        int rc = ffn(L.fs, "self_attn.ffn");
+        if (rc != KP2D_OK) return rc;
+      }
     }
     // ---- CrossBlock (lightglue.py:303-327): [to_qk | to_v] in one layer, attention both ways ----
     {
@@ -342,10 +357,15 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         t.prec = 1;
         LG_CHECK(launch_attention(t, st), "cross_attn");
       }
-      a = linear(L.to_out, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
-      LG_CHECK(launch_lg_linear(a, st), "cross_attn.to_out");
-      int rc = ffn(L.fc, "cross_attn.ffn");
-      if (rc != KP2D_OK) return rc;
+      if (fuse_tail && d == 32) {
+        int rc = tail(L.to_out, L.fc, "cross_attn tail");
+        if (rc != KP2D_OK) return rc;
+      } else {
+        a = linear(L.to_out, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
+        LG_CHECK(launch_lg_linear(a, st), "cross_attn.to_out");
+        int rc = ffn(L.fc, "cross_attn.ffn");
+        if (rc != KP2D_OK) return rc;
+      }
     }
   }
   {
