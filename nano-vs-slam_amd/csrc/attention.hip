@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
   for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  const float* kvb = a.kv + (size_t)b * T * kvs + a.k_off + h * d;
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + h * d;
 
   for (int kc = 0; kc < T; kc += AKT) {
     __syncthreads();
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs 
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const float* kvb = a.kv + (size_t)b * T * kvs + a.k_off + hd * d;
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
 
   for (int kc = 0; kc < T; kc += SKT) {
     __syncthreads();

@@ -128,6 +128,8 @@ struct AttnArgs {
   // v_off C, out_stride C).  The LightGlue blocks read q, k, v as slices of one [q|k|v] or [qk|v] row.
   int q_stride = 0, kv_stride = 0, k_off = 0, v_off = 0, out_stride = 0;
   int prec = 0;        // 1: split-fp16 operands on v_mfma_f32_32x32x16_f16 (head dim <= 16), 0: exact fp32 MFMA
+  int kv_bshift = 0;   // keys / values of batch item b come from item (b + kv_bshift) % B (LightGlue cross attention
+                       // of both directions in one launch: items [0,B/2) are image 0, [B/2,B) image 1)
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -328,13 +328,19 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
       LgLinArgs a = linear(L.qkv, X, d, d, nullptr, 0, 0, T3, 3 * d, R, 3 * d, LG_EPI_ROTARY);
       a.cs = CS; a.hd = hd; a.rot_cols = 2 * d;
       LG_CHECK(launch_lg_linear(a, st), "self_attn.Wqkv");
-      for (int set = 0; set < 2; ++set) {
-        const size_t r0 = set ? (size_t)R0 : 0;
-        const int n = set ? N : M;
-        AttnArgs t{T3 + r0 * 3 * d, T3 + r0 * 3 * d, CTX + r0 * d, B, n, n, d, heads, scale};
-        t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d;
-        t.prec = 1;      // split-fp16 MFMA (fp32-grade, attention.hip): 3x faster than the fp32 16x16x4 kernel at head dim 8
+      if (M == N) {   // both images as one batch of 2B sequences
+        AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
+        t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d; t.prec = 1;
         LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
+      } else {
+        for (int set = 0; set < 2; ++set) {
+          const size_t r0 = set ? (size_t)R0 : 0;
+          const int n = set ? N : M;
+          AttnArgs t{T3 + r0 * 3 * d, T3 + r0 * 3 * d, CTX + r0 * d, B, n, n, d, heads, scale};
+          t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d;
+          t.prec = 1;      // split-fp16 MFMA (fp32-grade, attention.hip): 3x faster than the fp32 16x16x4 kernel at head dim 8
+          LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
+        }
       }
       if (fuse_tail && d == 32) {
         int rc = tail(L.out_proj, L.fs, "self_attn tail");
@@ -350,12 +356,19 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     {
       LgLinArgs a = linear(L.qkv_x, X, d, d, nullptr, 0, 0, T3, 2 * d, R, 2 * d, LG_EPI_NONE);
       LG_CHECK(launch_lg_linear(a, st), "cross_attn.to_qk/to_v");
-      for (int set = 0; set < 2; ++set) {
-        const size_t rq = set ? (size_t)R0 : 0, rk = set ? 0 : (size_t)R0;
-        AttnArgs t{T3 + rq * 2 * d, T3 + rk * 2 * d, CTX + rq * d, B, set ? N : M, set ? M : N, d, heads, scale};
-        t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d;
-        t.prec = 1;
+      if (M == N) {   // both directions in one launch: sequence b attends to sequence (b + B) mod 2B
+        AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
+        t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d; t.prec = 1;
+        t.kv_bshift = B;
         LG_CHECK(launch_attention(t, st), "cross_attn");
+      } else {
+        for (int set = 0; set < 2; ++set) {
+          const size_t rq = set ? (size_t)R0 : 0, rk = set ? 0 : (size_t)R0;
+          AttnArgs t{T3 + rq * 2 * d, T3 + rk * 2 * d, CTX + rq * d, B, set ? N : M, set ? M : N, d, heads, scale};
+          t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d;
+          t.prec = 1;
+          LG_CHECK(launch_attention(t, st), "cross_attn");
+        }
       }
       if (fuse_tail && d == 32) {
         int rc = tail(L.to_out, L.fc, "cross_attn tail");

@@ -60,7 +60,9 @@ def check(pred, ref, conf, th):
 
 
 @pytest.mark.parametrize("name,B,M,N,th", [("S", 2, 70, 53, 0.1), ("S", 1, 300, 257, 0.0), ("F", 1, 128, 96, 0.1),
-                                           ("A", 3, 17, 64, 0.1)])
+                                           ("A", 3, 17, 64, 0.1),
+                                           # M == N: both images' attention runs as one launch of 2B sequences
+                                           ("S", 3, 96, 96, 0.1), ("S", 1, 200, 200, 0.0)])
 def test_lightglue_matches_oracle(name, B, M, N, th):
     from lightglue.lightglue_configs import get_light_glue_config
     conf_in = dict(get_light_glue_config(name), filter_threshold=th)
