@@ -158,8 +158,6 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
     if (k < K && q < CQ) v = reinterpret_cast<const float4*>(a.wa + (size_t)k * C)[q];
     *reinterpret_cast<float4*>(&s_w[k * VP + 4 * q]) = v;
   }
-  for (int e = tid; e < VT * 16; e += 256)   // zero once: padded channels stay zero for every tile
-    *reinterpret_cast<float4*>(&s_x[(e >> 4) * VP + 4 * (e & 15)]) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // wave -> blocks: step 1 (k-tile kt1, p-tile pt1), step 2 (k-tile kt2, c-tile ct2)
   const int kt1 = wave % KT, pt1 = wave / KT;          // KT == 2: 4 blocks; KT == 1: waves 0,1 only
@@ -171,27 +169,42 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   for (int r = 0; r < 16; ++r) vacc[r] = 0.f;
   float asum = 0.f;
   const int p4 = tid >> 2, q4 = tid & 3;               // 4 threads per pixel
-  const int cq = C >> 2, kq = K >> 2;
+  const int kq = K >> 2;
   const float* xb = a.x + (size_t)b * S * C;
+
+  // A thread owns channels [16 q4, 16 q4 + 16) of pixel p4 of the tile: it reads them straight from global memory
+  // (the next tile is fetched into registers while the two products of this one run), normalises in registers
+  // and writes the normalised descriptor to LDS once.
+  float4 v[4];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const int c = 16 * q4 + 4 * j4;
+      v[j4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t0 + p4 < s_end && c < C) v[j4] = *reinterpret_cast<const float4*>(xb + (size_t)(t0 + p4) * C + c);
+    }
+  };
+  fetch(s_begin);
 
   for (int t0 = s_begin; t0 < s_end; t0 += VT) {
     const int np = min(VT, s_end - t0);
-    __syncthreads();
-    for (int e = tid; e < VT * CQ; e += 256) {
-      const int pp = e / CQ, q = e - pp * CQ;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np) v = reinterpret_cast<const float4*>(xb + (size_t)(t0 + pp) * C)[q];
-      *reinterpret_cast<float4*>(&s_x[pp * VP + 4 * q]) = v;
-    }
-    __syncthreads();
+    __syncthreads();     // the previous tile's step 2 and row sums are done with s_x / s_a
     {  // descriptor-wise L2 normalisation (F.normalize, eps 1e-12)
       float ss = 0.f;
-      for (int c = q4 * cq; c < (q4 + 1) * cq; ++c) { const float v = s_x[p4 * VP + c]; ss = fmaf(v, v, ss); }
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        ss = fmaf(v[j4].x, v[j4].x, ss); ss = fmaf(v[j4].y, v[j4].y, ss);
+        ss = fmaf(v[j4].z, v[j4].z, ss); ss = fmaf(v[j4].w, v[j4].w, ss);
+      }
       ss += __shfl_xor(ss, 1);
       ss += __shfl_xor(ss, 2);
       const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-      for (int c = q4 * cq; c < (q4 + 1) * cq; ++c) s_x[p4 * VP + c] *= inv;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4)     // channels past C are written as zeros (v stayed 0)
+        *reinterpret_cast<float4*>(&s_x[p4 * VP + 16 * q4 + 4 * j4]) =
+            make_float4(v[j4].x * inv, v[j4].y * inv, v[j4].z * inv, v[j4].w * inv);
     }
+    if (t0 + VT < s_end) fetch(t0 + VT);
     __syncthreads();
     if (has1) {   // step 1: logits^T block (rows k, cols p)
       vf16 d;
@@ -249,27 +262,37 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   if (tid < K) dst[KC_ + tid] = asum;
 }
 
-__global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
+constexpr int FIN_T = 1024;   // threads of the finish workgroup: the partial sums are latency-bound reads, so go wide
+__global__ __launch_bounds__(FIN_T) void netvlad_finish_kernel(const VladArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C, K = a.K, KC_ = K * C;
   float* s_v = sm;            // [K*C]
   float* s_as = s_v + KC_;    // [K]
-  float* s_n = s_as + K;      // [K] row norms, then [4] wave sums
+  float* s_n = s_as + K;      // [K] row norms, then [FIN_T / 64] wave sums
   const int tid = threadIdx.x, b = blockIdx.x;
-  const float* base = a.part + (size_t)b * a.nsplit * (KC_ + K);
-  for (int e = tid; e < KC_ + K; e += 256) {
-    float s = 0.f;
-    for (int sp = 0; sp < a.nsplit; ++sp) s += base[(size_t)sp * (KC_ + K) + e];
-    s_v[e] = s;               // s_as follows s_v contiguously
+  const size_t ps = (size_t)KC_ + K;
+  const float* base = a.part + (size_t)b * a.nsplit * ps;
+  for (int e = tid; e < KC_ + K; e += FIN_T) {
+    // four independent chains keep four loads in flight per thread; the order of the sum is fixed
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < a.nsplit; sp += 4) {
+      s0 += base[(size_t)sp * ps + e];
+      s1 += base[(size_t)(sp + 1) * ps + e];
+      s2 += base[(size_t)(sp + 2) * ps + e];
+      s3 += base[(size_t)(sp + 3) * ps + e];
+    }
+    for (; sp < a.nsplit; ++sp) s0 += base[(size_t)sp * ps + e];
+    s_v[e] = (s0 + s1) + (s2 + s3);   // s_as follows s_v contiguously
   }
   __syncthreads();
-  for (int e = tid; e < KC_; e += 256) {
+  for (int e = tid; e < KC_; e += FIN_T) {
     const int k = e / C, c = e - k * C;
     s_v[e] = s_v[e] - s_as[k] * a.cent[k * C + c];
   }
   __syncthreads();
   // intra-normalisation: 4 threads per cluster row
-  for (int k = tid >> 2; k < K; k += 64) {
+  for (int k = tid >> 2; k < K; k += FIN_T / 4) {
     const int q = tid & 3, cq = C >> 2;
     float ss = 0.f;
     for (int c = q * cq; c < (q + 1) * cq; ++c) { const float v = s_v[k * C + c]; ss = fmaf(v, v, ss); }
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
   }
   __syncthreads();
   float tot = 0.f;
-  for (int e = tid; e < KC_; e += 256) {
+  for (int e = tid; e < KC_; e += FIN_T) {
     const float v = s_v[e] * s_n[e / C];
     s_v[e] = v;
     tot = fmaf(v, v, tot);
@@ -288,8 +311,11 @@ __global__ __launch_bounds__(256) void netvlad_finish_kernel(const VladArgs a) {
   __syncthreads();
   if ((tid & 63) == 0) s_n[tid >> 6] = tot;
   __syncthreads();
-  const float inv = 1.f / fmaxf(sqrtf(s_n[0] + s_n[1] + s_n[2] + s_n[3]), 1e-12f);
-  for (int e = tid; e < KC_; e += 256) a.out[(size_t)b * KC_ + e] = s_v[e] * inv;
+  float all = 0.f;
+#pragma unroll
+  for (int w = 0; w < FIN_T / 64; ++w) all += s_n[w];
+  const float inv = 1.f / fmaxf(sqrtf(all), 1e-12f);
+  for (int e = tid; e < KC_; e += FIN_T) a.out[(size_t)b * KC_ + e] = s_v[e] * inv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,8 +397,8 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(netvlad_partial_kernel<32>, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
     }
   }
-  const size_t lds2 = (size_t)(a.K * a.C + 2 * a.K + 8) * sizeof(float);
-  hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(256), lds2, s, a);
+  const size_t lds2 = (size_t)(a.K * a.C + a.K + (a.K > FIN_T / 64 ? a.K : FIN_T / 64) + 8) * sizeof(float);
+  hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(FIN_T), lds2, s, a);
   return (int)hipGetLastError();
 }
 
