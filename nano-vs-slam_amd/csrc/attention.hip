@@ -253,7 +253,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void att_split2(float x, float y, h16x2& hi, h16x2& lo) {
   const f32x2_ v = {x, y};
   hi = __builtin_convertvector(v, h16x2);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2_), h16x2);
+  // x - float(hi) as a mixed-precision fma (v_fma_mix_f32 reads the fp16 half directly): one instruction per
+  // element instead of a conversion and a subtraction; the result is the same (the product is exact)
+  f32x2_ r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hi), "v"(x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hi), "v"(y));
+  lo = __builtin_convertvector(r, h16x2);
 }
 __device__ __forceinline__ void att_split8(const float (&x)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
@@ -271,6 +276,7 @@ constexpr int SVP = 40;    // V^T row pitch in halves: 32 keys | 8 pad
 __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
   __shared__ __attribute__((aligned(16))) _Float16 Vt[(SKT / 32) * 16 * 2 * SVP];   // [tile][chan][hi|lo][SVP]
+  __shared__ __attribute__((aligned(16))) _Float16 Vc[16];                            // eight ones, eight zeros
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -292,7 +298,15 @@ __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs 
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
+  // Rows 16..31 of the V^T operand are padding (head dim <= 16).  Row 16 is set to ones, so that row 16 of O^T
+  // accumulates the softmax denominator sum_k (ph + pl) on the matrix cores; the other padding rows are zeros.
+  // Every lane reads its operand through a per-lane pointer (rows < 16: the staged V^T image, advancing per tile;
+  // padding rows: the constant block, not advancing), so the tile loop has no lane-dependent branch.
+  if (tid < 16) Vc[tid] = (_Float16)(tid < 8 ? 1.f : 0.f);
+  const _Float16* vph = (i < 16) ? &Vt[(i * 2) * SVP + 8 * h] : (i == 16 ? &Vc[0] : &Vc[8]);
+  const _Float16* vpl = (i < 16) ? vph + SVP : &Vc[8];
+  const int vstep = (i < 16) ? 16 * 2 * SVP : 0, vtoff = (i < 16) ? 16 : 0;
   const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
   const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
 
@@ -348,32 +362,26 @@ __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs 
       if (__any(mx != m)) {                     // running maxima moved for some query of this wave: rescale
         const float alpha = __builtin_amdgcn_exp2f(m - mx);       // first tile: exp2(-inf) = 0
         m = mx;
-        l *= alpha;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] *= alpha;          // rows >= 16 of O^T are padding and stay zero
+        for (int r = 0; r < 9; ++r) o[r] *= alpha;          // rows 0..15 (channels) and row 16 (denominator)
       }
       float p[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mx); l += p[r]; }
+      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         h16x8 ph, pl;
         const float (&pp)[8] = *reinterpret_cast<const float (*)[8]>(&p[8 * t]);
         att_split8(pp, ph, pl);
-        h16x8 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { vh[j] = (_Float16)0; vl[j] = (_Float16)0; }
-        if (i < 16) {
-          const _Float16* vt = &Vt[((t32 * 16 + i) * 2) * SVP + t * 16 + 8 * h];
-          vh = *reinterpret_cast<const h16x8*>(vt);
-          vl = *reinterpret_cast<const h16x8*>(vt + SVP);
-        }
+        const h16x8 vh = *reinterpret_cast<const h16x8*>(vph + t32 * vstep + t * vtoff);
+        const h16x8 vl = *reinterpret_cast<const h16x8*>(vpl + t32 * vstep + t * vtoff);
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
       }
     }
   }
+  float l = o[8];                 // row 16 of O^T lives in register 8 of the h = 0 lanes (row 20, zero, for h = 1)
   l += __shfl_xor(l, 32);
   if (qi < S) {
     const float inv = 1.f / l;
