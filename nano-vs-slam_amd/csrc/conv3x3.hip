@@ -79,6 +79,8 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
   float* s_w = smem + IN_ROWS * IN_PITCH * KCP;
 
   const int tid = threadIdx.x;
+  // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL: fp16 results that overflow clamp to +-65504
+  if (PREC == 1) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int i = lane & 31;
@@ -211,11 +213,11 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
         // the 64-byte block IS the LDS row
         *reinterpret_cast<float4*>(&s_in[st_lds[it] + st_q4]) = v;
       } else {
-        // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; |x| is clamped to the fp16 range
-        const float lim = 65000.f;
+        // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; conversions saturate at the fp16 range
+        // (MODE.FP16_OVFL, set at kernel entry) instead of producing infinities
         f16x2 h0, h1, l0, l1;
-        split2(__builtin_amdgcn_fmed3f(v.x, -lim, lim), __builtin_amdgcn_fmed3f(v.y, -lim, lim), h0, l0);
-        split2(__builtin_amdgcn_fmed3f(v.z, -lim, lim), __builtin_amdgcn_fmed3f(v.w, -lim, lim), h1, l1);
+        split2(v.x, v.y, h0, l0);
+        split2(v.z, v.w, h1, l1);
         _Float16* row = reinterpret_cast<_Float16*>(&s_in[st_lds[it]]);
         *reinterpret_cast<f16x4*>(row + st_q4) = f16x4{h0[0], h0[1], h1[0], h1[1]};
         *reinterpret_cast<f16x4*>(row + 16 + st_q4) = f16x4{l0[0], l0[1], l1[0], l1[1]};

@@ -501,3 +501,23 @@ def test_streams_views_and_coexisting_models():
         assert torch.equal(a2[k], ref2[k]), k
     for k in ("score", "coord", "feat", "seg"):
         assert torch.equal(b1[k], p1[k]), k
+
+
+def test_operand_split_saturates_instead_of_overflowing():
+    """Activations past the fp16 range: the split-fp16 convolutions convert with MODE.FP16_OVFL set, so the high half
+    saturates at 65504 (and the low half carries the rest up to 131008) instead of turning into inf - inf = NaN.
+    The reference is plain fp32 and stays finite for such inputs (its BatchNorm / sigmoid / tanh squash them)."""
+    model, sd = product_model("S", False, 28)
+    x = synthetic_frames(1, 32, 48, seed=5) * 3.0e5       # conv1a outputs land far past 65504
+    with torch.no_grad():
+        out = model(torch.from_numpy(x.astype(np.float32)).to(DEV))
+    for k in ("score", "coord", "feat", "seg", "vlad"):
+        assert bool(torch.isfinite(out[k]).all()), k
+    # moderately large activations (inside hi + lo's reach) still agree with the exact-fp32 mode of the same engine
+    x2 = synthetic_frames(1, 32, 48, seed=5) * 40.0
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in model(torch.from_numpy(x2.astype(np.float32)).to(DEV)).items()}
+        model.set_precision("fp32")
+        b = model(torch.from_numpy(x2.astype(np.float32)).to(DEV))
+    for k in ("score", "coord"):
+        assert float((a[k] - b[k]).abs().max()) < 1e-3, k
