@@ -220,12 +220,18 @@ def main():
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         total_ms = sum(v["ms"] for v in agg.values())
         split = "f16x3" in dom
-        # f16x3: one fp32-grade product = three fp16 MFMAs, so the algorithmic peak is the fp16 peak / 3
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        # f16x3: one fp32-grade product = three fp16 MFMAs, so the algorithmic peak is the fp16 peak / 3.
+        # The split attention kernel (head dim 16) additionally runs its P.V product on 32x32 tiles of which 16 rows
+        # are channels and the rest padding: 9 MFMAs (3 for S, 6 for P.V) per 2*32*32*16*2 algorithmic FLOPs = 2/9.
+        mfma_per_flop = (2.0 / 9.0) if dom == "attention_f16x3" else (1.0 / 3.0)
+        peak = PEAK_F16_MFMA_TFLOPS * mfma_per_flop if split else PEAK_F32_MFMA_TFLOPS
+        note = ("dense fp16 MFMA 2516.6 TFLOP/s x 2/9 (split attention, head dim 16: 9 fp16 MFMAs per 32x32 score tile)"
+                if dom == "attention_f16x3" else
+                "dense fp16 MFMA 2516.6 TFLOP/s / 3 MFMAs per fp32-grade product (xh*wh + xh*wl + xl*wh)"
+                if split else "fp32 MFMA v_mfma_f32_32x32x2_f32")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                "peak_note": ("dense fp16 MFMA 2516.6 TFLOP/s / 3 MFMAs per fp32-grade product (xh*wh + xh*wl + xl*wh)"
-                              if split else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                "peak_note": note,
                 "launches_per_step": a["launches"] // args.profile_steps,
                 "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                 "share_of_kernel_time": round(a["ms"] / total_ms, 4),
@@ -234,7 +240,7 @@ def main():
         if split:
             # a bare fp16 MFMA loop sustains 1571 TFLOP/s on this chip (clock drops to ~1.5 GHz under matrix load:
             # tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log) -> 523.7 TFLOP/s of fp32-grade products
-            roof["frac_of_sustained_mfma"] = round(achieved / (1571.0 / 3.0), 4)
+            roof["frac_of_sustained_mfma"] = round(achieved / (1571.0 * mfma_per_flop), 4)
         # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_collect.sh): bench.py
         # cannot run rocprofv3 around itself, so the per-launch figure measured on this workload is read back
         try:

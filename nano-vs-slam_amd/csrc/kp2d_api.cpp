@@ -660,7 +660,7 @@ struct Plan {
       AttnArgs a{ptr(q), ptr(kv), ptr(ao), B, h * w, (h / 2) * (w / 2), C, heads, 1.0f / std::sqrt((float)(C / heads))};
       a.prec = m->precision == KP2D_PREC_F16X3 ? 1 : 0;
       const double st = (double)B * h * w * (h / 2) * (w / 2);
-      prof_begin(p + ".att.fn", "attention", 4.0 * st * C, 4.0 * B * ((double)2 * h * w * C + (h / 2) * (w / 2) * 2.0 * C));
+      prof_begin(p + ".att.fn", (a.prec == 1 && C / heads <= 16) ? "attention_f16x3" : "attention", 4.0 * st * C, 4.0 * B * ((double)2 * h * w * C + (h / 2) * (w / 2) * 2.0 * C));
       check(launch_attention(a, stream), (p + ".att.fn").c_str());
       prof_end();
     }
