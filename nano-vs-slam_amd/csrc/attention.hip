@@ -8,6 +8,8 @@
 //                              written; K/V are walked in 64-key LDS chunks with an online softmax.
 //  * dwconv3x3_kernel          depthwise 3x3 + bias of MixFeedForward's DsConv2d (segformer.py:45-59)
 // The 1x1 convolutions (to_q, to_out, MixFFN) and the 2x2 stride-2 to_kv run through conv3x3.hip with taps = 1.
+#include <cstdlib>
+
 #include "kp2d_kernels.h"
 
 namespace kp2d {
@@ -273,7 +275,8 @@ constexpr int SKT = 128;   // keys per LDS chunk (four 32-key tiles)
 constexpr int SKP = 40;    // K row pitch in halves: 16 hi | 16 lo | 8 pad  (80 B)
 constexpr int SVP = 40;    // V^T row pitch in halves: 32 keys | 8 pad
 
-__global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs a) {
+template <int NTHR, int WPS>   // threads per workgroup (32 queries per wave), waves per SIMD asked of the compiler
+__global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
   __shared__ __attribute__((aligned(16))) _Float16 Vt[(SKT / 32) * 16 * 2 * SVP];   // [tile][chan][hi|lo][SVP]
   __shared__ __attribute__((aligned(16))) _Float16 Vc[16];                            // eight ones, eight zeros
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs 
   const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
   const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
-  const int qi = blockIdx.x * 128 + wave * 32 + i;
+  const int qi = blockIdx.x * (NTHR / 2) + wave * 32 + i;
   // Q^T operand: lane (query i, h) holds channels 8h..8h+7, pre-multiplied by scale * log2(e) so that the
   // softmax runs on exp2 directly
   h16x8 qh, ql;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256, 5) void attention_split_kernel(const AttnArgs 
   for (int kc = 0; kc < T; kc += SKT) {
     __syncthreads();
     // stage: granule e = (key, 4 channels).  K row-major split rows; V transposed with the slot permutation.
-    for (int e = tid; e < SKT * 4; e += 256) {
+    for (int e = tid; e < SKT * 4; e += NTHR) {
       const int key = e >> 2, q4 = e & 3;
       float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
       if (kc + key < T && 4 * q4 < d) {
@@ -405,7 +408,13 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
   const int d = a.C / a.heads;
   if (a.C % a.heads || d > 64 || (d & 3) || (a.C & 3)) return -1402;
   if (a.prec == 1 && d <= 16) {
-    hipLaunchKernelGGL(attention_split_kernel, dim3((a.S + 127) / 128, a.heads, a.B), dim3(256), 0, s, a);
+    // 256 queries per workgroup halve the K / V staging per query (18 % of the kernel at 128); short sequences
+    // keep 128 so that the grid still covers the chip
+    static const int big = getenv("KP2D_ATT_Q") ? atoi(getenv("KP2D_ATT_Q")) : 256;
+    if (big == 256 && (long)((a.S + 255) / 256) * a.heads * a.B >= 512)
+      hipLaunchKernelGGL((attention_split_kernel<512, 6>), dim3((a.S + 255) / 256, a.heads, a.B), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((attention_split_kernel<256, 5>), dim3((a.S + 127) / 128, a.heads, a.B), dim3(256), 0, s, a);
     return (int)hipGetLastError();
   }
   const dim3 grid((a.S + 63) / 64, a.heads, a.B);
