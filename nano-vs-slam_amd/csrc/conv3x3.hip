@@ -366,13 +366,8 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <int CO>
 __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_w[27 * CO];
-  __shared__ float s_sc[CO], s_sh[CO];
   __shared__ __attribute__((aligned(16))) float4 s_o[256 * 4];
   static_assert(CO == 16, "conv1a: the output staging assumes 16 channels (4 float4 per pixel)");
-  for (int t = threadIdx.x; t < 27 * CO; t += 256) s_w[t] = a.w[t];
-  for (int t = threadIdx.x; t < CO; t += 256) { s_sc[t] = a.scale[t]; s_sh[t] = a.shift[t]; }
-  __syncthreads();
   const int H = a.H, W = a.W;
   const size_t npix = (size_t)a.B * H * W;
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -383,39 +378,48 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    // 27 taps as buffer loads: a tap outside the image gets an offset past the descriptor's range, which the
+    // hardware answers with 0 — no lane-dependent branches (the ternary form compiled to 64 exec-mask branches).
+    // The descriptor covers this block's frames only (offsets stay 32-bit for any batch size).
     float v[27];
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
-      const float* plane = a.x + ((size_t)b * 3 + ci) * H * W;
+    {
+      const size_t fb = ((size_t)blockIdx.x * 256) / ((size_t)W * H);          // first frame this block touches
+      const size_t frames_left = (size_t)a.B - fb;
+      const size_t nf = 256 / ((size_t)W * H) + 2;                              // frames a 256-pixel block can touch
+      const size_t span = (frames_left < nf ? frames_left : nf) * 3 * (size_t)H * W * sizeof(float);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.x + fb * 3 * (size_t)H * W), 0, (int)span, 0x00020000);
+      const int fo = ((b - (int)fb) * 3 * H * W) * 4;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int yy = y + dy - 1;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int xx = x + dx - 1;
-          v[ci * 9 + dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? plane[(size_t)yy * W + xx] : 0.f;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const int o = ok ? fo + (yy * W + xx) * 4 : 0x7ffffff0;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci)      // the plane stride goes into the scalar offset
+            v[ci * 9 + dy * 3 + dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, ci * H * W * 4, 0));
         }
       }
     }
-    // k stays a real loop: fully unrolled, hipcc keeps all 27*CO weights live in registers
+    // The weight row of a tap is the same for every lane: read it with a uniform index so that it arrives
+    // through the scalar cache in SGPRs (s_load_dwordx16) and feeds the FMAs as a scalar operand.  As LDS
+    // broadcast reads (4 ds_read_b128 per tap per wave) the weights alone kept the LDS array busy for ~75 us
+    // of this kernel.
+    const float* wg = a.w;
 #pragma unroll 3
     for (int k = 0; k < 27; ++k) {
-      const float4* wr = reinterpret_cast<const float4*>(&s_w[k * CO]);
       const float vk = v[k];
 #pragma unroll
-      for (int c = 0; c < CO; c += 4) {
-        const float4 w4 = wr[c / 4];
-        acc[c] = fmaf(vk, w4.x, acc[c]);
-        acc[c + 1] = fmaf(vk, w4.y, acc[c + 1]);
-        acc[c + 2] = fmaf(vk, w4.z, acc[c + 2]);
-        acc[c + 3] = fmaf(vk, w4.w, acc[c + 3]);
-      }
+      for (int c = 0; c < CO; ++c) acc[c] = fmaf(vk, wg[k * CO + c], acc[c]);
     }
     // BatchNorm affine + LeakyReLU / ReLU / identity as max(v, v*slope)
     const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
-      const float t = fmaf(acc[c], s_sc[c], s_sh[c]);
+      const float t = fmaf(acc[c], a.scale[c], a.shift[c]);     // uniform index: scalar loads
       acc[c] = fmaxf(t, t * slope);
     }
     if (a.out_s16) {
