@@ -520,6 +520,9 @@ __global__ __launch_bounds__(256) void conv1a_wide_kernel(const Conv1aArgs a) {
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
   const size_t npix = (size_t)a.B * a.H * a.W;
   const int grid = (int)((npix + 255) / 256);
+  // conv1a_kernel addresses its taps with 32-bit byte offsets inside a descriptor of at most
+  // 256 / (H W) + 2 frames
+  if ((256 / ((size_t)a.H * a.W) + 2) * 3 * (size_t)a.H * a.W * sizeof(float) >= 0x7ffffff0u) return -1002;
   if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cout % 16 == 0 && a.cout <= 256 && !a.out_s16)
     hipLaunchKernelGGL(conv1a_wide_kernel, dim3(grid), dim3(256), (size_t)29 * a.cout * sizeof(float), s, a);
