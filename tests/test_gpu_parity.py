@@ -87,6 +87,7 @@ def test_against_reference_golden(name, precision):
 @pytest.mark.parametrize("config,v3,ncls,B,H,W", [
     ("S", False, 28, 3, 72, 104),     # ragged: tiles hang over every edge
     ("S", False, 5, 1, 16, 16),       # smallest legal frame, few classes
+    ("S", False, 28, 5, 16, 24),      # 384-pixel frames: every 256-pixel conv1a block straddles a frame boundary
     ("N", False, 28, 2, 40, 56),      # K=32 C=48, KC=8 path, padded channel groups
     ("S", True, 19, 2, 48, 80),       # V3 fused heads + Softmax2d
     ("N", True, 28, 1, 64, 64),
