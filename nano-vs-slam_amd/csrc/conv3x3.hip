@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
   // Software pipeline over K chunks: the global loads of chunk c+1 are issued into registers before the
   // MFMA loop of chunk c and only written to LDS (with the fp32 -> hi/lo split in PREC 1) after it, so the
   // L2/HBM latency hides under the matrix-core work of this wave and of the co-resident workgroup.
-  constexpr int IN_G = IN_ROWS * IN_ROWS * Q;
+  // A 1x1 convolution reads only the centre 16x16 pixels of the LDS image: stage those (at their halo-offset
+  // positions, so the operand reads are the same code) instead of the 18x18 halo tile — 21 % fewer loads,
+  // splits and LDS writes, 4 staging iterations instead of 6.
+  constexpr int ST_ROWS = TAPS == 1 ? 16 : IN_ROWS;
+  constexpr int ST_OFF = TAPS == 1 ? 1 : 0;
+  constexpr int IN_G = ST_ROWS * ST_ROWS * Q;
   constexpr int IN_IT = (IN_G + 255) / 256;
   constexpr int W_G = STAPS * N * Q;      // weight granules per stage
   constexpr int W_IT = (W_G + 255) / 256;
@@ -140,7 +145,8 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
   for (int it = 0; it < IN_IT; ++it) {
     const int g = tid + 256 * it;
     const int p = g / Q;
-    const int py = p / IN_ROWS, px = p - py * IN_ROWS;
+    const int sy = p / ST_ROWS;
+    const int py = sy + ST_OFF, px = p - sy * ST_ROWS + ST_OFF;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
     const bool ok = g < IN_G && gy >= 0 && gy < H && gx >= 0 && gx < W;
     st_off0[it] = ok ? ((int)(gy * a.in0.rs + gx * a.in0.ps) + st_q4) * 4 : OOB;
