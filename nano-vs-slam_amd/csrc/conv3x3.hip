@@ -346,7 +346,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   // npad is 32, or a multiple of 64 handled as npad/64 channel groups (blockIdx.y)
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
-  const bool one = a.npad == 32;
+  const bool one = a.npad == 32 || a.ng32;
   if (a.prec == 1) {
     if (kc != 16) return -1003;
     static const bool wst3 = !(getenv("KP2D_WST") && getenv("KP2D_WST")[0] == '1');

@@ -64,6 +64,7 @@ struct ConvPack {
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
   size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows, scale * 2^-11
+  size_t w16n_off = 0;                        // the same rows in 32-channel groups (npad >= 64): small-grid launches
   size_t w16s_off = 0;                        // same rows, staged order [chunk][dy][dx][n] + quad swizzle (conv_s16.hip)
   bool s16_capable() const { return kind == 0 && (cin % 16) == 0; }
   size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
@@ -151,6 +152,7 @@ struct kp2d_model {
                           // round 1: the producer-side split costs more in the exposed epilogue than it saves in
                           // the (hidden) staging conversion: 14.7k vs 15.5k frames/s, so fp32 activations stay default.
   bool profiling = false;
+  bool small_grid_ng32 = !(getenv("KP2D_NG32") && getenv("KP2D_NG32")[0] == '0');   // KP2D_NG32=0: always 64-channel groups
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
   hipStream_t prof_stream = nullptr;
@@ -350,6 +352,7 @@ int describe(kp2d_model* m) {
     c.sc_off = take(c.npad);
     c.sh_off = take(c.npad);
     c.w16_off = take(c.w16_floats());
+    if (c.npad >= 64) c.w16n_off = take(c.w16_floats());
     c.sc16_off = take(c.npad);
     if (c.s16_capable()) c.w16s_off = take(c.w16_floats());
   }
@@ -482,6 +485,12 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
             const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + tap) * ng + n) * 32;   // in halves
             h16[row + kk] = hi;
             h16[row + 16 + kk] = lo;
+            if (c.npad >= 64) {   // 32-channel groups of the same rows
+              _Float16* n16 = reinterpret_cast<_Float16*>(&blob[c.w16n_off]);
+              const size_t rown = ((((size_t)(q / 32) * nchunk16 + chk) * c.taps + tap) * 32 + (q % 32)) * 32;
+              n16[rown + kk] = hi;
+              n16[rown + 16 + kk] = lo;
+            }
             if (c.s16_capable()) {
               // conv_s16.hip: slab per (chunk, dy) = rows r = dx*ng + n; 16-byte quad j of a row
               // (0: hi k0-7, 1: hi k8-15, 2: lo k0-7, 3: lo k8-15) is stored at position j ^ ((r >> 2) & 3)
@@ -585,12 +594,19 @@ struct Plan {
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
     a.w = m->blob + (dma ? c.w16s_off : (split ? c.w16_off : c.w_off));
+    a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
+    // Small grids (a frame or two at a time): a 64-channel-group launch would leave most CUs idle and each of its
+    // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
+    if (split && !dma && !in_s16 && c.npad >= 64 && m->small_grid_ng32 &&
+        (long)a.tiles_x * a.tiles_y * B * (c.npad / 64) < 256) {
+      a.w = m->blob + c.w16n_off;
+      a.ng32 = 1;
+    }
     a.scale = m->blob + (split ? c.sc16_off : c.sc_off);
     a.shift = m->blob + c.sh_off;
     a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
     a.B = B; a.H = Hc; a.W = Wc; a.cin = c.cin; a.cout = c.cout; a.npad = c.npad;
     a.act = act; a.store = store; a.nsplit = nsplit;
-    a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
     const char* fam = dma ? "conv3x3_s16dma" : split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")

@@ -46,6 +46,7 @@ struct ConvArgs {
   int cin, cout, npad;
   int act, store, nsplit;
   int tiles_x, tiles_y;
+  int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip stores, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA
 };
 

@@ -20,6 +20,8 @@ namespace kp2d {
 constexpr int VT = 64;  // pixels per LDS tile
 
 int netvlad_nsplit(int S) {
+  // Depends on the frame size only: the order of the partial sums (and with it the last bits of the descriptor)
+  // must not change with the batch or sub-batch a frame happens to travel in (test_full_size_properties).
   static const int per = getenv("KP2D_VLAD_PX") ? atoi(getenv("KP2D_VLAD_PX")) : 320;   // pixels per workgroup (tuning knob)
   int n = (S + per - 1) / per;
   return n < 1 ? 1 : n;
