@@ -920,14 +920,15 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.release(cp);
     } else {
       const int ns = netvlad_nsplit(S);
+      const int tps = netvlad_tiles_per_slab(S, B);
       Act part{};
-      part.bytes = (size_t)B * ns * ((size_t)K * C + K) * sizeof(float);
+      part.bytes = (size_t)B * (ns * tps + (tps > 1 ? 1 : 0)) * ((size_t)K * C + K) * sizeof(float);   // tile mode: + the ordered sums
       part.off = P.arena.alloc(part.bytes);
       if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
       if (!P.dry && P.rc == KP2D_OK) {
         VladArgs a{};
         a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
-        a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns;
+        a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns; a.tps = tps;
         P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
         P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
         P.prof_end();

@@ -70,12 +70,14 @@ struct VladArgs {
   float* part;           // workspace [B][nsplit][K*C + K]
   float* out;            // [B][K*C]
   int B, S, C, K, nsplit;
+  int tps = 1;           // > 1: one workgroup per 64-pixel tile, tps tiles per slab (netvlad_tiles_per_slab); part holds nsplit*tps rows
 };
 int launch_netvlad(const VladArgs& a, hipStream_t s);
 struct PoolArgs { const float* x; const float* p; float* out; int B, C, Hc, Wc; };   // GeM (p = exponent) / ConvAP pooling
 int launch_gem(const PoolArgs& a, hipStream_t s);
 int launch_convap_pool(const PoolArgs& a, hipStream_t s);
 int netvlad_nsplit(int S);
+int netvlad_tiles_per_slab(int S, int B);
 
 // ---- post-processing (models/kp2dtiny.py:593-647 / 959-1015) -------------------------------
 struct PostArgs {

@@ -27,6 +27,17 @@ int netvlad_nsplit(int S) {
   return n < 1 ? 1 : n;
 }
 
+// Workgroups per slab.  1: a workgroup walks its whole slab.  > 1 (few frames per call, where nsplit workgroups per
+// frame would leave the chip idle): one workgroup per 64-pixel tile of the slab; the finish pass then adds the
+// tile partials of a slab in tile order before it adds the slabs — the same additions in the same order as a
+// workgroup walking the slab, so the result does not depend on which mode a frame was processed in.
+int netvlad_tiles_per_slab(int S, int B) {
+  const int ns = netvlad_nsplit(S);
+  if ((long)B * ns >= 256) return 1;
+  const int per = (S + ns - 1) / ns;
+  return (per + VT - 1) / VT;
+}
+
 // NOWN = (cluster, channel) accumulators per thread: K*C <= 256*NOWN
 template <int NOWN>
 __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) {
@@ -39,8 +50,10 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
   const int tid = threadIdx.x;
   const int b = blockIdx.y, split = blockIdx.x;
   const int per = (S + a.nsplit - 1) / a.nsplit;
-  const int s_begin = split * per;
-  const int s_end = min(S, s_begin + per);
+  const int tps = a.tps > 1 ? a.tps : 1;                 // tile mode: blockIdx.x = slab * tps + tile
+  const int slab = split / tps;
+  const int s_begin = slab * per + (split - slab * tps) * (a.tps > 1 ? VT : 0);
+  const int s_end = a.tps > 1 ? min(min(S, slab * per + per), s_begin + VT) : min(S, s_begin + per);
 
   for (int e = tid; e < K * C; e += 256) s_w[(e / C) * CP + (e % C)] = a.wa[e];
 
@@ -107,16 +120,19 @@ __global__ __launch_bounds__(256) void netvlad_partial_kernel(const VladArgs a) 
 #pragma unroll
     for (int j = 0; j < NOWN; ++j) {
       if (j < nown) {
-        float acc = vacc[j];
+        float acc = 0.f;                        // the tile's own sum first, then into the slab's (see tiles_per_slab)
         const int k = vk[j], c = vc[j];
         for (int pp = 0; pp < VT; ++pp) acc = fmaf(s_a[pp * KP + k], s_x[pp * CP + c], acc);
-        vacc[j] = acc;
+        vacc[j] += acc;
       }
     }
-    if (tid < K)
-      for (int pp = 0; pp < VT; ++pp) asum += s_a[pp * KP + tid];
+    if (tid < K) {
+      float at = 0.f;
+      for (int pp = 0; pp < VT; ++pp) at += s_a[pp * KP + tid];
+      asum += at;
+    }
   }
-  float* dst = a.part + ((size_t)b * a.nsplit + split) * (KC_ + K);
+  float* dst = a.part + ((size_t)b * gridDim.x + split) * (KC_ + K);
 #pragma unroll
   for (int j = 0; j < NOWN; ++j) {
     const int e = tid + 256 * j;
@@ -150,8 +166,10 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.y, split = blockIdx.x;
   const int per = (S + a.nsplit - 1) / a.nsplit;
-  const int s_begin = split * per;
-  const int s_end = min(S, s_begin + per);
+  const int tps = a.tps > 1 ? a.tps : 1;                 // tile mode: blockIdx.x = slab * tps + tile
+  const int slab = split / tps;
+  const int s_begin = slab * per + (split - slab * tps) * (a.tps > 1 ? VT : 0);
+  const int s_end = a.tps > 1 ? min(min(S, slab * per + per), s_begin + VT) : min(S, s_begin + per);
   const int CQ = C >> 2;
 
   for (int e = tid; e < KPAD * 16; e += 256) {
@@ -245,14 +263,22 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
     if (has2) {   // step 2: V block (rows k, cols c), contraction over the tile's 64 pixels
       const float* ar = &s_a[(32 * h) * AP + kt2 * 32 + i];
       const float* xr = &s_x[(32 * h) * VP + ct2 * 32 + i];
+      vf16 vt;                                   // the tile's own sum first, then into the slab's (see tiles_per_slab)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vt[r] = 0.f;
 #pragma unroll 8
-      for (int s = 0; s < 32; ++s) vacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s * AP], xr[s * VP], vacc, 0, 0, 0);
+      for (int s = 0; s < 32; ++s) vt = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s * AP], xr[s * VP], vt, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vacc[r] += vt[r];
     }
-    if (tid < K)
-      for (int pp = 0; pp < VT; ++pp) asum += s_a[pp * AP + tid];
+    if (tid < K) {
+      float at = 0.f;
+      for (int pp = 0; pp < VT; ++pp) at += s_a[pp * AP + tid];
+      asum += at;
+    }
   }
   const int KC_ = K * C;
-  float* dst = a.part + ((size_t)b * a.nsplit + split) * (KC_ + K);
+  float* dst = a.part + ((size_t)b * gridDim.x + split) * (KC_ + K);
   if (has2) {
     const int c = ct2 * 32 + i;
 #pragma unroll
@@ -264,6 +290,51 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   if (tid < K) dst[KC_ + tid] = asum;
 }
 
+// Sum of a frame's partials for element e of [K*C + K], in ONE fixed order whatever produced them: a slab's value
+// is the sum of its tile partials in tile order (tile mode; exactly what a slab-walking workgroup accumulates), and
+// the slabs go into four interleaved chains (four loads in flight per thread) that are added as (s0 + s1) + (s2 + s3).
+__device__ __forceinline__ float vlad_ordered_sum(const VladArgs& a, int b, int e) {
+  const size_t ps = (size_t)a.K * a.C + a.K;
+  const int tps = a.tps > 1 ? a.tps : 1;
+  const float* base = a.part + (size_t)b * a.nsplit * tps * ps;
+  auto slab = [&](int sp) {
+    const float* q = base + (size_t)sp * tps * ps + e;
+    if (tps == 1) return q[0];
+    if (tps <= 8) {     // all tile partials in flight at once, then added in tile order
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = i < tps ? q[(size_t)i * ps] : 0.f;
+      float v = t[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i)
+        if (i < tps) v += t[i];
+      return v;
+    }
+    float v = q[0];
+    for (int t = 1; t < tps; ++t) v += q[(size_t)t * ps];
+    return v;
+  };
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sp = 0;
+  for (; sp + 3 < a.nsplit; sp += 4) {
+    s0 += slab(sp);
+    s1 += slab(sp + 1);
+    s2 += slab(sp + 2);
+    s3 += slab(sp + 3);
+  }
+  for (; sp < a.nsplit; ++sp) s0 += slab(sp);
+  return (s0 + s1) + (s2 + s3);
+}
+
+// Tile mode only (few frames per call): the ordered sums spread over many workgroups — one finish workgroup per
+// frame reading nsplit*tps partials was 54 us for a single frame.  Writes sums[b][K*C + K]; the finish pass then
+// runs on those as a single "partial" per frame (0 + v is exact).
+__global__ __launch_bounds__(256) void netvlad_sum_kernel(const VladArgs a, float* sums) {
+  const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const int n = a.K * a.C + a.K;
+  if (e < n) sums[(size_t)b * n + e] = vlad_ordered_sum(a, b, e);
+}
+
 constexpr int FIN_T = 1024;   // threads of the finish workgroup: the partial sums are latency-bound reads, so go wide
 __global__ __launch_bounds__(FIN_T) void netvlad_finish_kernel(const VladArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -272,21 +343,7 @@ __global__ __launch_bounds__(FIN_T) void netvlad_finish_kernel(const VladArgs a)
   float* s_as = s_v + KC_;    // [K]
   float* s_n = s_as + K;      // [K] row norms, then [FIN_T / 64] wave sums
   const int tid = threadIdx.x, b = blockIdx.x;
-  const size_t ps = (size_t)KC_ + K;
-  const float* base = a.part + (size_t)b * a.nsplit * ps;
-  for (int e = tid; e < KC_ + K; e += FIN_T) {
-    // four independent chains keep four loads in flight per thread; the order of the sum is fixed
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sp = 0;
-    for (; sp + 3 < a.nsplit; sp += 4) {
-      s0 += base[(size_t)sp * ps + e];
-      s1 += base[(size_t)(sp + 1) * ps + e];
-      s2 += base[(size_t)(sp + 2) * ps + e];
-      s3 += base[(size_t)(sp + 3) * ps + e];
-    }
-    for (; sp < a.nsplit; ++sp) s0 += base[(size_t)sp * ps + e];
-    s_v[e] = (s0 + s1) + (s2 + s3);   // s_as follows s_v contiguously
-  }
+  for (int e = tid; e < KC_ + K; e += FIN_T) s_v[e] = vlad_ordered_sum(a, b, e);   // s_as follows s_v contiguously
   __syncthreads();
   for (int e = tid; e < KC_; e += FIN_T) {
     const int k = e / C, c = e - k * C;
@@ -382,12 +439,12 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
   if ((a.K == 32 || a.K == 64) && a.C <= 64) {
     const int kt = a.K / 32;
     const size_t lds = (size_t)(32 * kt * VP + VT * VP + VT * AP) * sizeof(float);
-    if (kt == 2) hipLaunchKernelGGL(netvlad_partial_mfma_kernel<2>, dim3(a.nsplit, a.B), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(netvlad_partial_mfma_kernel<1>, dim3(a.nsplit, a.B), dim3(256), lds, s, a);
+    if (kt == 2) hipLaunchKernelGGL(netvlad_partial_mfma_kernel<2>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(netvlad_partial_mfma_kernel<1>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds, s, a);
   } else {
     const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
     if (a.K * a.C <= 4096) {
-      hipLaunchKernelGGL(netvlad_partial_kernel<16>, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+      hipLaunchKernelGGL(netvlad_partial_kernel<16>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds1, s, a);
     } else {   // TINY_F: 64 clusters x 128 channels, 83 KB of LDS
       static bool attr_done = false;
       if (!attr_done) {
@@ -396,11 +453,20 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
       }
-      hipLaunchKernelGGL(netvlad_partial_kernel<32>, dim3(a.nsplit, a.B), dim3(256), lds1, s, a);
+      hipLaunchKernelGGL(netvlad_partial_kernel<32>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds1, s, a);
     }
   }
   const size_t lds2 = (size_t)(a.K * a.C + a.K + (a.K > FIN_T / 64 ? a.K : FIN_T / 64) + 8) * sizeof(float);
-  hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(FIN_T), lds2, s, a);
+  if (a.tps > 1) {
+    const int n = a.K * a.C + a.K;
+    float* sums = a.part + (size_t)a.B * a.nsplit * a.tps * n;     // the plan reserves B*n floats behind the partials
+    hipLaunchKernelGGL(netvlad_sum_kernel, dim3((n + 255) / 256, a.B), dim3(256), 0, s, a, sums);
+    VladArgs f = a;
+    f.part = sums; f.nsplit = 1; f.tps = 1;
+    hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(FIN_T), lds2, s, f);
+  } else {
+    hipLaunchKernelGGL(netvlad_finish_kernel, dim3(a.B), dim3(FIN_T), lds2, s, a);
+  }
   return (int)hipGetLastError();
 }
 
