@@ -41,4 +41,9 @@ step "LightGlue"
 timeout -k 10 200 python3 tools/bench_lightglue.py 2>/dev/null | tail -1 > "$OUT/lightglue.jsonl"
 timeout -k 10 200 python3 tools/bench_lightglue.py --pairs 1 2>/dev/null | tail -1 >> "$OUT/lightglue.jsonl"
 cut -c1-200 "$OUT/lightglue.jsonl"
+step "PCIe-inclusive front-end"
+timeout -k 10 200 python3 tools/bench_frontend.py 2>/dev/null | tail -1 > "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --pinned 2>/dev/null | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 200 2>/dev/null | tail -1 >> "$OUT/frontend.jsonl"
+cut -c1-200 "$OUT/frontend.jsonl"
 step done
