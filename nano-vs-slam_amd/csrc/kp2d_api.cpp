@@ -60,6 +60,7 @@ struct ConvPack {
   bool bias = true;     // plain conv only: has a .bias tensor
   bool tconv = false;   // TransposedConvUpsampleModel (base.py:80-117) restated as a pixel-shuffled 3x3 conv (add_tconv)
   int kind = 0;         // 0: 3x3 [co][ci][3][3]   1: 1x1 [co][ci][1][1]   2: 2x2 stride 2 [co][ci][2][2] as 1x1 over 4*ci
+  std::vector<std::pair<std::string, int>> parts;   // merged CBRs over one input (name, cout): rows = the parts' rows in order
   int taps = 9;
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
@@ -118,6 +119,7 @@ struct Arena {
 struct Act {
   size_t off = 0, bytes = 0;
   int C = 0, H = 0, W = 0;
+  int PS = 0, CO = 0;  // channel-slice view of a wider tensor: pixel stride (0 = C) and first channel; bytes = 0 (not owned)
   bool s16 = false;   // pre-split [16 hi | 16 lo] fp16 blocks (conv_common.h) instead of fp32; same byte size
 };
 
@@ -326,6 +328,19 @@ int describe(kp2d_model* m) {
   add_cbr(m, "vlad_head.convlad1", c4, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad2", g.encoder_dim, g.encoder_dim);
   add_cbr(m, "vlad_head.convlad3", g.encoder_dim, g.encoder_dim);
+  {
+    // The first CBR of every head reads the same backbone map: one launch computes them all (rows of the parts
+    // back to back), the heads then read channel slices of its output.  The attention seg heads keep their own
+    // launch (their first CBR feeds a LayerNorm, which wants a dense tensor).
+    ConvPack mg;
+    mg.name = "heads.first"; mg.bn = true; mg.cin = c4;
+    auto part = [&](const std::string& n) { mg.parts.emplace_back(n, m->convs[m->conv_index.at(n)].cout); mg.cout += mg.parts.back().second; };
+    if (v3) part("score_loc_head.convDa");
+    else { part("score_head.convDa"); part("loc_head.convDa"); part("desc_head.convA"); }
+    if (!g.use_attention && m->conv_index.count("seg_head.convs.0")) part("seg_head.convs.0");
+    part("vlad_head.convlad1");
+    if (mg.parts.size() >= 2) { m->conv_index[mg.name] = (int)m->convs.size(); m->convs.push_back(mg); }
+  }
   const bool has_vlad = g.global_descriptor == KP2D_GD_NETVLAD && !g.remove_netvlad;
   if (has_vlad) {
     add_spec(m, "vlad_head.netvlad.centroids", {g.num_clusters, g.encoder_dim});
@@ -414,9 +429,20 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
                       wt[(((size_t)ci * cq4 + co) * 3 + ky) * 3 + kx];
                 }
     }
-    const auto& w = c.tconv ? wvirt : *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][ci][k][k]
     std::vector<float> sc(c.cout), sh(c.cout);
-    if (c.tconv) {
+    if (!c.parts.empty()) {   // rows of the parts, back to back
+      wvirt.reserve((size_t)c.cout * c.cin * 9);
+      int row = 0;
+      for (const auto& pt : c.parts) {
+        const auto& wp = *host_get(m, pt.first + ".conv.weight");
+        wvirt.insert(wvirt.end(), wp.begin(), wp.end());
+        bn_fold(m, pt.first + ".bn", pt.second, sc.data() + row, sh.data() + row);
+        row += pt.second;
+      }
+    }
+    const auto& w = (c.tconv || !c.parts.empty()) ? wvirt : *host_get(m, c.name + (c.bn ? ".conv.weight" : ".weight"));   // [cout][ci][k][k]
+    if (!c.parts.empty()) {
+    } else if (c.tconv) {
       std::vector<float> s4(c.cout / 4), h4(c.cout / 4);
       bn_fold(m, c.name + ".bn", c.cout / 4, s4.data(), h4.data());
       for (int i = 0; i < c.cout; ++i) { sc[i] = s4[i / 4]; sh[i] = h4[i / 4]; }
@@ -546,7 +572,12 @@ struct Plan {
     if (a.off == (size_t)-1 && rc == KP2D_OK) rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
     return a;
   }
-  void release(const Act& a) { arena.release(a.off, a.bytes); }
+  void release(const Act& a) { if (a.bytes) arena.release(a.off, a.bytes); }
+  static Act view(const Act& parent, int c, int o) {   // channels [o, o + c) of parent; released by releasing the parent
+    Act v = parent;
+    v.bytes = 0; v.C = c; v.PS = parent.PS ? parent.PS : parent.C; v.CO = parent.CO + o;
+    return v;
+  }
   float* ptr(const Act& a) const { return reinterpret_cast<float*>(ws + a.off); }
 
   void prof_begin(const std::string& layer, const char* kernel, double flops, double bytes) {
@@ -573,8 +604,9 @@ struct Plan {
 
   static ConvSrc dense(const float* p, const Act& t, int c, int o) {
     ConvSrc s{};
-    s.p = p; s.c = c; s.o = o;
-    s.ps = t.C; s.rs = (long)t.W * t.C; s.bs = (long)t.H * t.W * t.C;
+    const int ps = t.PS ? t.PS : t.C;
+    s.p = p; s.c = c; s.o = o + t.CO;
+    s.ps = ps; s.rs = (long)t.W * ps; s.bs = (long)t.H * t.W * ps;
     return s;
   }
   // core launch: sources already described
@@ -778,21 +810,40 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   const int Hc = xb.H, Wc = xb.W, H2 = skip.H, W2 = skip.W;
 
   const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;   // only_encoder(): skip every head but the VPR encoder
+  // First CBR of every head in one launch ("heads.first", see describe()); first(name) hands out its channel slices.
+  static const bool merge_env = !(getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '0');
+  // Only where a head's own launch would be a small grid (a frame or two per call): there the five launches are five
+  // serial latencies (0.42 -> 0.37 ms per frame); at 32 frames per launch the strided slice reads cost what the
+  // fuller grid gains (20.43k vs 20.36k frames/s).
+  const bool small_grid = (long)((Hc + 15) / 16) * ((Wc + 15) / 16) * P.B < 256;
+  const bool merged = merge_env && small_grid && !only_enc && !P.s16_mode && m->conv_index.count("heads.first");
+  Act mx{};
+  if (merged) mx = P.cbr("heads.first", xb, nullptr, ST_NHWC);
+  auto first = [&](const std::string& name, bool s16out = true) -> Act {
+    if (merged) {
+      int o = 0;
+      for (const auto& pt : m->convs[m->conv_index.at("heads.first")].parts) {
+        if (pt.first == name) return Plan::view(mx, pt.second, o);
+        o += pt.second;
+      }
+    }
+    return P.cbr(name, xb, nullptr, ST_NHWC, nullptr, s16out);
+  };
   // ---- score / location heads (heads.py:28-35; sigmoid/tanh kp2dtiny.py:574-575, :927-935) ----
   if (only_enc) {
   } else if (v3) {
-    Act s1 = P.cbr("score_loc_head.convDa", xb, nullptr, ST_NHWC);
+    Act s1 = first("score_loc_head.convDa");
     P.conv("score_loc_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID0_TANH, ST_NCHW, o.score, 0, 0, o.shift, 0, 0, 1, Hc, Wc);
     P.release(s1);
   } else {
-    Act s1 = P.cbr("score_head.convDa", xb, nullptr, ST_NHWC);
+    Act s1 = first("score_head.convDa");
     P.conv("score_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID, ST_NCHW, o.score, 0, 0, nullptr, 0, 0, 1, Hc, Wc);
     P.release(s1);
-    Act l1 = P.cbr("loc_head.convDa", xb, nullptr, ST_NHWC);
+    Act l1 = first("loc_head.convDa");
     P.conv("loc_head.convDb", l1, l1.C, 0, nullptr, ACT_TANH, ST_NCHW, o.shift, 0, 0, nullptr, 0, 0, 2, Hc, Wc);
     P.release(l1);
     // ---- descriptor head (heads.py:91-104) ----
-    Act d1 = P.cbr("desc_head.convA", xb, nullptr, ST_NHWC);
+    Act d1 = first("desc_head.convA");
     const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
     Act d2 = P.alloc(cB.cout / 4, H2, W2);
     d2.s16 = P.s16_mode;
@@ -844,7 +895,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.release(g4);
       i = 5;
     } else {
-      Act g0 = P.cbr(L + "0", xb, nullptr, ST_NHWC);
+      Act g0 = first(L + "0");
       Act g1 = P.cbr(L + "1", g0, nullptr, ST_NHWC_POOL);
       P.release(g0);
       Act g2 = P.cbr(L + "2", g1, nullptr, ST_NHWC);
@@ -889,7 +940,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
 
   // ---- VPR head (vpr.py:78-89) + NetVLAD (netvlad.py:79-106) ----
   {
-    Act v1 = P.cbr("vlad_head.convlad1", xb, nullptr, ST_NHWC);
+    Act v1 = first("vlad_head.convlad1");
     Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
     P.release(v1);
     Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // NetVLAD reads fp32
@@ -937,6 +988,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     }
     P.release(v3a);
   }
+  if (merged) P.release(mx);
   P.release(xb);
   P.release(skip);
 }
