@@ -15,6 +15,7 @@
 namespace kp2d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // one wave per pixel, lane = channels lane, lane+64, ... (C <= 64*NV): the channel reduction is a 6-step butterfly
 template <int NV>
@@ -109,6 +110,8 @@ int launch_channel_layernorm(const LnArgs& a, hipStream_t s) {
 
 // depthwise 3x3, pad 1, bias; NHWC.  One thread per (4 consecutive pixels of a row, 4 channels): the 3 x 6 input window
 // is loaded once for the four outputs (18 sixteen-byte loads instead of 36) and the 9 x C weights sit in LDS.
+constexpr int DW_R = 4;   // output rows per thread: 6 input rows feed 4 output rows (2.25 window loads per output
+                          // float4 instead of 4.5 — the vertical reuse came out of L2 before, which bounded the kernel)
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_dw[];   // [9][C] weights, [C] bias
   const int C = a.C, Q = C >> 2, H = a.H, W = a.W;
@@ -116,48 +119,73 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
     reinterpret_cast<float4*>(s_dw)[e] = e < 9 * Q ? reinterpret_cast<const float4*>(a.w)[e]
                                                     : reinterpret_cast<const float4*>(a.bias)[e - 9 * Q];
   __syncthreads();
-  const int WG4 = (W + 3) >> 2;                                   // pixel groups per row
-  const long total = (long)a.B * H * WG4 * Q;
+  const int WG4 = (W + 3) >> 2;                                   // 4-pixel groups per row
+  const int HG = (H + DW_R - 1) / DW_R;                           // row groups per frame
+  const long total = (long)a.B * HG * WG4 * Q;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int q = (int)(e % Q);
   const long grp = e / Q;
   const int xg = (int)(grp % WG4);
-  const long rowi = grp / WG4;                                    // b * H + y
-  const int y = (int)(rowi % H);
+  const long rg = grp / WG4;                                      // b * HG + row group
+  const int b = (int)(rg / HG);
+  const int y0 = (int)(rg - (long)b * HG) * DW_R;
   const int x0 = 4 * xg;
   const float4 bias = reinterpret_cast<const float4*>(s_dw + 9 * C)[q];
-  float4 acc[4] = {bias, bias, bias, bias};
-  const float* base = a.x + (rowi * W) * C;                       // row y of this frame
+  float4 acc[DW_R][4];
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= H) continue;
+  for (int r = 0; r < DW_R; ++r)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[r][p] = bias;
+  // Window loads as buffer loads with 32-bit offsets from the first frame this block touches; a tap outside the
+  // image gets an offset past the descriptor, which reads as zeros (the zero padding): no 64-bit address
+  // arithmetic and no exec-mask branch per tap.
+  const long fb = ((long)blockIdx.x * 256 / Q / WG4) / HG;
+  const size_t fbytes = (size_t)H * W * C * sizeof(float);
+  const size_t nf = (size_t)(256 * 4 * DW_R) / ((size_t)H * W) + 2;      // frames a 256-thread block can touch
+  const size_t fl = (size_t)a.B - (size_t)fb;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)fb * H * W * C, 0, (int)((fl < nf ? fl : nf) * fbytes), 0x00020000);
+  const int fo = (int)((b - fb) * (long)fbytes) + q * 16;
+#pragma unroll
+  for (int r = -1; r <= DW_R; ++r) {          // input row y0 + r feeds output rows r-1, r, r+1 of the group
+    const int yy = y0 + r;
+    const bool yok = yy >= 0 && yy < H;
     float4 v[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int xx = x0 - 1 + j;
-      v[j] = (xx >= 0 && xx < W) ? reinterpret_cast<const float4*>(base + ((long)dy * W + xx) * C)[q]
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int o = (yok && xx >= 0 && xx < W) ? fo + (yy * W + xx) * C * 4 : 0x7ffffff0;
+      v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
     }
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const float4 w = reinterpret_cast<const float4*>(s_dw + ((dy + 1) * 3 + dx) * C)[q];
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int orow = r - dy;                 // output row (in the group) that sees this input row at offset dy
+      if (orow < 0 || orow >= DW_R) continue;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        acc[p].x = fmaf(v[p + dx].x, w.x, acc[p].x); acc[p].y = fmaf(v[p + dx].y, w.y, acc[p].y);
-        acc[p].z = fmaf(v[p + dx].z, w.z, acc[p].z); acc[p].w = fmaf(v[p + dx].w, w.w, acc[p].w);
+      for (int dx = 0; dx < 3; ++dx) {
+        const float4 w = reinterpret_cast<const float4*>(s_dw + ((dy + 1) * 3 + dx) * C)[q];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          acc[orow][p].x = fmaf(v[p + dx].x, w.x, acc[orow][p].x); acc[orow][p].y = fmaf(v[p + dx].y, w.y, acc[orow][p].y);
+          acc[orow][p].z = fmaf(v[p + dx].z, w.z, acc[orow][p].z); acc[orow][p].w = fmaf(v[p + dx].w, w.w, acc[orow][p].w);
+        }
       }
     }
   }
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-    if (x0 + p < W) reinterpret_cast<float4*>(a.y + (rowi * W + x0 + p) * C)[q] = acc[p];
+  for (int r = 0; r < DW_R; ++r)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (y0 + r < H && x0 + p < W)
+        reinterpret_cast<float4*>(a.y + (((size_t)b * H + y0 + r) * W + x0 + p) * C)[q] = acc[r][p];
 }
 
 int launch_dwconv3x3(const DwArgs& a, hipStream_t s) {
   if ((a.C & 3) || a.C > 1024) return -1401;
-  const long total = (long)a.B * a.H * ((a.W + 3) >> 2) * (a.C >> 2);
+  // 32-bit byte offsets inside a descriptor of at most 256 * 4 * DW_R / (H W) + 2 frames
+  if (((size_t)(256 * 4 * DW_R) / ((size_t)a.H * a.W) + 2) * a.H * a.W * a.C * sizeof(float) >= 0x7ffffff0u) return -1403;
+  const long total = (long)a.B * ((a.H + DW_R - 1) / DW_R) * ((a.W + 3) >> 2) * (a.C >> 2);
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), (size_t)10 * a.C * sizeof(float), s, a);
   return (int)hipGetLastError();
 }
