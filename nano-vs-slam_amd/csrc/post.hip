@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
   for (int e = tid; e < kpow; e += 256) s_keys[e] = 0ull;
 
   unsigned long long thresh = ~0ull;   // nothing selected
-  if (count > 0) {
+  if (ncand <= (unsigned)a.k) {
+    thresh = 1ull;                     // every candidate is selected (keys of candidates are non-zero): no rank to find
+  } else if (count > 0) {
     if (tid == 0) { s_prefix = 0ull; s_rank = count; s_done = 0u; }
     __syncthreads();
     for (int pass = 7; pass >= 0; --pass) {
@@ -273,10 +275,12 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
     }
   }
   __syncthreads();
-  // bitonic sort, descending
-  for (int size = 2; size <= kpow; size <<= 1) {
+  // bitonic sort, descending, of the smallest power-of-two prefix that holds the selected keys (the rest are zeros)
+  int ksort = 2;
+  while (ksort < (int)count) ksort <<= 1;
+  for (int size = 2; size <= ksort; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (kpow >> 1); t += 256) {
+      for (int t = tid; t < (ksort >> 1); t += 256) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = ((lo & size) == 0);
