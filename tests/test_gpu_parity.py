@@ -522,3 +522,34 @@ def test_operand_split_saturates_instead_of_overflowing():
         b = model(torch.from_numpy(x2.astype(np.float32)).to(DEV))
     for k in ("score", "coord"):
         assert float((a[k] - b[k]).abs().max()) < 1e-3, k
+
+
+def test_selection_edge_cases():
+    """Edges of K1/K2/K3 (the reference thresholds first and only ranks when more than k cells survive,
+    evaluation/visual_odometry.py:106-117): nothing above the threshold, fewer candidates than k (no ranking needed),
+    k larger than the number of cells, and a frame where every cell is selected."""
+    from nano_vs_slam_amd.selectors import gather_keypoints, select_topk
+    rng = np.random.default_rng(3)
+    B, Hc, Wc, Cd = 3, 6, 8, 32
+    n = Hc * Wc
+    score = rng.random((B, 1, Hc, Wc), dtype=np.float32) * 0.5          # all below 0.7
+    score[1, 0].reshape(-1)[[5, 17, 30]] = [0.9, 0.8, 0.95]             # frame 1: three candidates
+    score[2] = 0.75 + 0.2 * rng.random((1, Hc, Wc), dtype=np.float32)  # frame 2: every cell above the threshold
+    coord = rng.random((B, 2, Hc, Wc), dtype=np.float32) * 100
+    desc = rng.standard_normal((B, Cd, Hc, Wc)).astype(np.float32)
+    s, c, d = (torch.from_numpy(t).to(DEV) for t in (score, coord, desc))
+    for k in (4, 10, 1000):                                              # 1000 > n: clipped to n by the host wrapper
+        idx, val, cnt = select_topk(s, k, 0.7)
+        kk = min(k, n)
+        assert idx.shape == (B, kk) and cnt.tolist() == [0, min(3, kk), kk]
+        assert (idx[0] == -1).all() and (val[0] == 0).all()
+        order1 = [30, 5, 17][:kk]
+        assert idx[1, :len(order1)].tolist() == order1 and (idx[1, len(order1):] == -1).all()
+        ref2 = np.argsort(-score[2].reshape(-1), kind="stable")[:kk]
+        assert idx[2].cpu().numpy().tolist() == ref2.tolist()
+        assert np.array_equal(val[2].cpu().numpy(), score[2].reshape(-1)[ref2])
+        pts, dsel = gather_keypoints(c, d, idx)
+        assert (pts[0] == 0).all() and (dsel[0] == 0).all()              # unselected slots gather zeros
+        got = dsel[2].cpu().numpy()
+        assert np.array_equal(got, desc[2].reshape(Cd, -1)[:, ref2].T)
+        assert np.array_equal(pts[2].cpu().numpy(), coord[2].reshape(2, -1)[:, ref2].T)
