@@ -553,3 +553,22 @@ def test_selection_edge_cases():
         got = dsel[2].cpu().numpy()
         assert np.array_equal(got, desc[2].reshape(Cd, -1)[:, ref2].T)
         assert np.array_equal(pts[2].cpu().numpy(), coord[2].reshape(2, -1)[:, ref2].T)
+
+
+@pytest.mark.parametrize("config,v3,B,H,W", [
+    ("S", False, 1, 104, 136), ("S", False, 5, 56, 72), ("S", True, 2, 88, 120), ("S_A", True, 1, 120, 160),
+    ("S_A", False, 3, 64, 96), ("N", False, 1, 120, 160), ("N_A", True, 2, 72, 88), ("S", False, 9, 240, 320),
+])
+def test_precision_modes_agree_on_other_shapes(config, v3, B, H, W):
+    """The split-fp16 path takes shape-dependent routes the exact-fp32 path does not (32-channel groups and the merged
+    first layer of the heads for small grids, NetVLAD tile mode, centre-only staging of 1x1 convolutions, 256-query
+    attention workgroups): both modes of the engine must agree on shapes the fixtures do not cover."""
+    model, _ = product_model(config, v3, 19)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=31)).to(DEV)
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in model(x).items()}
+        model.set_precision("fp32")
+        b = model(x)
+    for k in ("score", "coord", "feat", "seg", "vlad"):
+        assert a[k].shape == b[k].shape
+        assert float((a[k] - b[k]).abs().max()) < TOL, k
