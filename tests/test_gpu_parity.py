@@ -558,6 +558,7 @@ def test_selection_edge_cases():
 @pytest.mark.parametrize("config,v3,B,H,W", [
     ("S", False, 1, 104, 136), ("S", False, 5, 56, 72), ("S", True, 2, 88, 120), ("S_A", True, 1, 120, 160),
     ("S_A", False, 3, 64, 96), ("N", False, 1, 120, 160), ("N_A", True, 2, 72, 88), ("S", False, 9, 240, 320),
+    ("S_A", True, 8, 240, 320),       # 19 query tiles x 4 heads x 8 frames >= 512 workgroups: the 256-query attention variant
 ])
 def test_precision_modes_agree_on_other_shapes(config, v3, B, H, W):
     """The split-fp16 path takes shape-dependent routes the exact-fp32 path does not (32-channel groups and the merged
