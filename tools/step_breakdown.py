@@ -1,5 +1,17 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Wall time of the bench step's parts in the bench setting (two lanes, 64 frames 240x320): forward only,
+forward + post_processing, and the full step (+ top-k selection and gather).
+
+    python3 tools/step_breakdown.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
 from nano_vs_slam_amd.selectors import gather_keypoints, select_topk
 from nano_vs_slam_amd.synthetic import spread_state_dict
