@@ -21,15 +21,45 @@ import sys
 
 import numpy as np
 
+import importlib.util
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO)
-sys.path.insert(0, "/root/reference")
+REFERENCE = "/root/reference"
 sys.dont_write_bytecode = True
+# The repo root holds import ALIASES named like the reference's packages (src/, lightglue/): it must never be on
+# sys.path while the reference is imported, or "from src.kp2dtiny..." resolves to the product.  The oracle's own
+# modules are therefore loaded by file path, and every repo path (also the script directory and "") is dropped.
+sys.path[:] = [REFERENCE] + [p for p in sys.path
+                             if p not in ("", ".", REFERENCE) and not os.path.abspath(p).startswith(REPO)]
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
 
 import torch  # noqa: E402
 
-from oracle import kp2d_oracle as orc  # noqa: E402
-from oracle.weights import spread_state_dict, synthetic_frames  # noqa: E402
+orc = _load_by_path("_golden_kp2d_oracle", os.path.join(REPO, "oracle", "kp2d_oracle.py"))
+_weights = _load_by_path("_golden_weights", os.path.join(REPO, "oracle", "weights.py"))
+spread_state_dict, synthetic_frames = _weights.spread_state_dict, _weights.synthetic_frames
+
+
+def reference_module():
+    """The reference's model module — and nothing else: refuses to run against anything outside /root/reference."""
+    import src.kp2dtiny.models.kp2dtiny as ref
+    where = os.path.realpath(ref.__file__)
+    if not where.startswith(REFERENCE + os.sep):
+        raise RuntimeError(f"make_golden.py imported {where}: fixtures must come from the reference under {REFERENCE}, "
+                           "never from this repo's aliases")
+    for name, mod in list(sys.modules.items()):
+        f = getattr(mod, "__file__", None)
+        if (name == "src" or name.startswith("src.")) and f and not os.path.realpath(f).startswith(REFERENCE + os.sep):
+            raise RuntimeError(f"module {name} resolved to {f}, outside the reference")
+    return ref
 
 # name -> (config, v3, n_classes, H, W, B, frame seed, smooth, dense stride, taps?)
 CASES = {
@@ -39,6 +69,7 @@ CASES = {
     "v2_S_120x160": ("S", False, 28, 120, 160, 2, 8, False, 1, False),
     "v2_S_240x320": ("S", False, 28, 240, 320, 2, 7, False, 4, False),      # BASELINE cfg 1/2 shape
     "v2_S_240x320_smooth": ("S", False, 28, 240, 320, 1, 9, True, 4, False),
+    "v2_S_480x640": ("S", False, 28, 480, 640, 1, 8, False, 8, False),      # BASELINE cfg 5's extractor shape
     "v2_SA_120x160": ("S_A", False, 28, 120, 160, 1, 8, False, 2, False),
     "v3_S_120x160": ("S", True, 19, 120, 160, 1, 8, False, 2, False),
     "v3_SA_240x320": ("S_A", True, 28, 240, 320, 1, 7, False, 4, False),    # demo.py config
@@ -65,7 +96,8 @@ CASES = {
 
 
 def build_reference(config, v3, n_classes):
-    from src.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory
+    ref = reference_module()
+    KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory = ref.KP2DTinyV2, ref.KP2DTinyV3, ref.get_config, ref.tiny_factory
     base, *mods = config.split("+")
     with contextlib.redirect_stdout(io.StringIO()):
         if "depth" in mods:
