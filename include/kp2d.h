@@ -121,7 +121,9 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
 /* replaces the callers' selectors: threshold + top-k on the cell grid, batched and on device
  * (evaluation/visual_odometry.py:105-117 K1, evaluation/descriptor.py:12-36 K2,
  *  gluefactory/models/extractors/kp2dtiny.py:38-42 K3).  Order: score descending, flat index ascending.
- *   score [B,n]; idx [B,k] (-1 padded); val [B,k] or NULL; count [B]; thr = -INFINITY for plain top-k; k <= 4096 */
+ *   score [B,n]; idx [B,k] (-1 padded); val [B,k] or NULL; count [B]; thr = -INFINITY for plain top-k.
+ *   Any k >= 1: the reference's "no cap" (top_k <= 0: every cell above thr, frontend.py:122) is k = n.  k <= 16384
+ *   selects and sorts in LDS; larger k sorts in place in the idx row (slower, same result). */
 int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t* idx, float* val, int32_t* count,
                      void* stream);
 /* gather the selected cells: pts [B,k,2] (x,y), dsel [B,k,C]; rows of padded (-1) entries are zero */

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["conv3x3.hip", "conv_s16.hip", "netvlad.hip", "post.hip", "attention.hip", "match.hip", "lightglue.hip", "kp2d_api.cpp",
            "lightglue_api.cpp"]
-HEADERS = ["kp2d_kernels.h", "conv_common.h", "conv_epilogue.inc", os.path.join("..", "..", "include", "kp2d.h"),
+HEADERS = ["kp2d_kernels.h", "device_guard.h", "conv_common.h", "conv_epilogue.inc", os.path.join("..", "..", "include", "kp2d.h"),
            os.path.join("..", "..", "include", "kp2d_lightglue.h")]
 LIB = os.path.join(HERE, "libkp2d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

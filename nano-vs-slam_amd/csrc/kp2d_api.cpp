@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "device_guard.h"
 #include "kp2d_kernels.h"
 
 using namespace kp2d;
@@ -64,7 +65,7 @@ struct ConvPack {
   int taps = 9;
   int cin = 0, cout = 0, npad = 0, kc = 16;   // cin = GEMM K per tap (4*ci for kind 2)
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
-  size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows, scale * 2^-11
+  size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows of w * 2^e, scale * 2^-e (pack())
   size_t w16n_off = 0;                        // the same rows in 32-channel groups (npad >= 64): small-grid launches
   size_t w16s_off = 0;                        // same rows, staged order [chunk][dy][dx][n] + quad swizzle (conv_s16.hip)
   bool s16_capable() const { return kind == 0 && (cin % 16) == 0; }
@@ -485,14 +486,25 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
     }
     (void)ngroups;
     // split-fp16 pack (conv3x3.hip PREC 1): K walked in chunks of 16; each row is 16 hi halves then 16 lo
-    // halves of w * 2^11; the epilogue scale carries the 2^-11.
+    // halves of w * 2^e; the epilogue scale carries the 2^-e.  e = 11 keeps the lo half of ordinary weights a normal
+    // fp16; a layer with large weights (|w| * 2^11 would pass the fp16 range: |w| >= 16) takes the largest e that keeps
+    // |w| * 2^e <= 2^15, so no checkpoint can turn a weight into inf (hi) / -inf (lo) silently.  Powers of two: the
+    // products and the fp32 accumulation are the same bits up to the exponent, whatever e is.
     {
+      float wmax = 0.f;
+      for (float v : w) {
+        if (!std::isfinite(v)) return fail(KP2D_ERR_WEIGHT, "%s: non-finite weight value", c.name.c_str());
+        wmax = std::max(wmax, std::fabs(v));
+      }
+      int e16 = 11;
+      while (e16 > -96 && wmax * std::ldexp(1.0f, e16) > 32768.0f) --e16;
+      const float wscale = std::ldexp(1.0f, e16), wunscale = std::ldexp(1.0f, -e16);
       _Float16* h16 = reinterpret_cast<_Float16*>(&blob[c.w16_off]);
       const int nchunk16 = (c.cin + 15) / 16;
       for (int q = 0; q < c.npad; ++q) {
         int co = -1;
         if (q < c.cout) co = c.shuffle ? 4 * (q % cq) + (q / cq) : q;
-        blob[c.sc16_off + q] = co >= 0 ? sc[co] * (1.0f / 2048.0f) : 0.f;
+        blob[c.sc16_off + q] = co >= 0 ? sc[co] * wunscale : 0.f;
         if (co < 0) continue;
         const int grp = q / ng, n = q % ng;
         for (int ci = 0; ci < c.cin; ++ci) {
@@ -505,7 +517,7 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
               const int Cq = c.cin / 4, dy = ci / (2 * Cq), dx = (ci / Cq) & 1, cc = ci % Cq;
               wv = w[(((size_t)co * Cq + cc) * 2 + dy) * 2 + dx];
             }
-            wv *= 2048.0f;
+            wv *= wscale;
             const _Float16 hi = (_Float16)wv;
             const _Float16 lo = (_Float16)(wv - (float)hi);
             const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + tap) * ng + n) * 32;   // in halves
@@ -1120,7 +1132,7 @@ int kp2d_finalize_weights(kp2d_model* m) {
   std::vector<float> blob;
   int rc = pack(m, blob);
   if (rc != KP2D_OK) return rc;
-  HIP_TRY(hipSetDevice(m->cfg.device));
+  DeviceGuard guard(m->cfg.device);
   if (!m->blob) HIP_TRY(hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float)));
   HIP_TRY(hipMemcpy(m->blob, blob.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice));
   m->finalized = true;
@@ -1132,13 +1144,14 @@ size_t kp2d_packed_bytes(const kp2d_model* m) { return m ? m->blob_floats * size
 int kp2d_export_packed(const kp2d_model* m, void* dev_dst, void* stream) {
   if (!m || !dev_dst) return fail(KP2D_ERR_ARG, "null argument");
   if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised");
+  DeviceGuard guard(m->cfg.device);
   HIP_TRY(hipMemcpyAsync(dev_dst, m->blob, m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return KP2D_OK;
 }
 
 int kp2d_import_packed(kp2d_model* m, const void* dev_src, void* stream) {
   if (!m || !dev_src) return fail(KP2D_ERR_ARG, "null argument");
-  HIP_TRY(hipSetDevice(m->cfg.device));
+  DeviceGuard guard(m->cfg.device);
   if (!m->blob) HIP_TRY(hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(m->blob, dev_src, m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1203,9 +1216,9 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
   hipStream_t caller = (hipStream_t)stream;
   m->prof_used = 0;
   m->prof_stream = caller;
+  DeviceGuard guard(g.device);
   // fork: lanes 1.. run on internal streams that start after everything already queued on the caller's stream
   if (nl > 1) {
-    HIP_TRY(hipSetDevice(g.device));
     while ((int)m->lane_streams.size() < nl - 1) {
       hipStream_t st; hipEvent_t ev;
       HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1217,7 +1230,8 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     for (int k = 1; k < nl; ++k) HIP_TRY(hipStreamWaitEvent(m->lane_streams[k - 1], m->fork_event, 0));
   }
   int ci = 0;
-  for (int b0 = 0; b0 < B; b0 += chunk, ++ci) {
+  rc = KP2D_OK;
+  for (int b0 = 0; b0 < B && rc == KP2D_OK; b0 += chunk, ++ci) {
     const int lane = ci % nl;
     Plan P{};
     P.m = m; P.stream = lane == 0 ? caller : m->lane_streams[lane - 1];
@@ -1234,14 +1248,19 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     o.vlad = vlad + (size_t)b0 * (only_enc ? (size_t)g.encoder_dim * Hc * Wc : kp2d_vlad_dim(m, H, W));
     o.depth = depth ? depth + (size_t)b0 * H2 * W2 : nullptr;
     build(P, o, flags);
-    if (P.rc != KP2D_OK) return P.rc;
+    rc = P.rc;
   }
-  // join: the caller's stream continues only after every lane has drained
+  // join: the caller's stream continues only after every lane has drained.  This also runs when a launch failed
+  // part-way: kernels already queued on the internal streams still write the caller's workspace and outputs, so the
+  // caller's stream (and whoever frees those buffers in stream order after the error) must be ordered behind them.
+  std::string first_err = rc != KP2D_OK ? g_err : std::string();
   for (int k = 1; k < nl; ++k) {
-    HIP_TRY(hipEventRecord(m->lane_events[k - 1], m->lane_streams[k - 1]));
-    HIP_TRY(hipStreamWaitEvent(caller, m->lane_events[k - 1], 0));
+    hipError_t e = hipEventRecord(m->lane_events[k - 1], m->lane_streams[k - 1]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(caller, m->lane_events[k - 1], 0);
+    if (e != hipSuccess && rc == KP2D_OK) rc = fail(KP2D_ERR_HIP, "lane join: %s", hipGetErrorString(e));
   }
-  return KP2D_OK;
+  if (!first_err.empty()) g_err = first_err;
+  return rc;
 }
 
 int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,
@@ -1250,6 +1269,7 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
   if (!m || !score || !shift || !score_out || !coord) return fail(KP2D_ERR_ARG, "null argument");
   if (desc && !feat) return fail(KP2D_ERR_ARG, "desc requested without feat");
   if (seg_ids && !seg) return fail(KP2D_ERR_ARG, "seg_ids requested without seg");
+  DeviceGuard guard(m->cfg.device);
   PostArgs a{};
   a.score_in = score; a.shift = shift; a.feat = feat; a.score_out = score_out; a.coord = coord; a.desc = desc;
   a.B = B; a.C = feat_c; a.Hc = Hc; a.Wc = Wc; a.Hf = Hf; a.Wf = Wf; a.H = H; a.W = W;
@@ -1273,7 +1293,9 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
 int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t* idx, float* val, int32_t* count,
                      void* stream) {
   if (!score || !idx || !count) return fail(KP2D_ERR_ARG, "null argument");
-  if (k < 1 || k > 4096) return fail(KP2D_ERR_ARG, "k must be in [1,4096]");
+  if (B < 1 || n < 1) return fail(KP2D_ERR_ARG, "empty score map (B=%d, n=%d)", B, n);
+  if (k < 1) return fail(KP2D_ERR_ARG, "k must be >= 1 (pass k = n for \"every cell above the threshold\")");
+  DeviceGuard guard(score);
   TopkArgs a{score, B, n, k, thr, idx, val, count};
   int e = launch_topk(a, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "topk kernel: %d", e);
@@ -1283,6 +1305,7 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
 int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
                           float* pts, float* dsel, void* stream) {
   if (!coord || !desc || !idx || !pts || !dsel) return fail(KP2D_ERR_ARG, "null argument");
+  DeviceGuard guard(coord);
   GatherArgs a{coord, desc, idx, pts, dsel, B, C, n, k};
   int e = launch_gather(a, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "gather kernel: %d", e);
@@ -1291,6 +1314,7 @@ int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* 
 
 int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int H, int W, void* stream) {
   if (!frames || !x || B < 1 || Hs < 1 || Ws < 1 || H < 1 || W < 1) return fail(KP2D_ERR_ARG, "bad preprocess arguments");
+  DeviceGuard guard(frames);
   int e = launch_preprocess(frames, x, B, Hs, Ws, H, W, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "preprocess kernel: %d", e);
   return KP2D_OK;
@@ -1302,6 +1326,7 @@ int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, 
   if (!d0 || !n0 || !d1 || !n1 || !nn_idx || !nn_dist || !nn_dist2 || !match_q || !match_d || !scratch)
     return fail(KP2D_ERR_ARG, "null argument");
   if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
+  DeviceGuard guard(d0);
   MatchArgs a{d0, d1, n0, n1, B, max0, max1, C, ratio, nn_idx, nn_dist, nn_dist2,
               reinterpret_cast<unsigned long long*>(scratch), match_q, match_d};
   int e = launch_match(a, (hipStream_t)stream);

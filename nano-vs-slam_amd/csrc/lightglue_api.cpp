@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "device_guard.h"
 #include "kp2d_kernels.h"
 
 using namespace kp2d;
@@ -242,7 +243,7 @@ int kp2d_lg_finalize_weights(kp2d_lg* m) {
   std::vector<float> blob;
   int rc = pack(m, blob);
   if (rc != KP2D_OK) return rc;
-  HIP_TRY(hipSetDevice(m->cfg.device));
+  kp2d::DeviceGuard guard(m->cfg.device);
   if (!m->blob) HIP_TRY(hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float)));
   HIP_TRY(hipMemcpy(m->blob, blob.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice));
   m->finalized = true;
@@ -266,6 +267,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
   if ((uintptr_t)workspace % ALIGN) return fail(KP2D_ERR_WORKSPACE, "workspace must be %zu-byte aligned", ALIGN);
   const Ws w = layout(m, B, M, N);
   if (workspace_bytes < w.total) return fail(KP2D_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
+  kp2d::DeviceGuard guard(m->cfg.device);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)workspace;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };

@@ -180,9 +180,15 @@ int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // top-k: one workgroup per frame.  Keys are 64-bit (order-preserving score bits << 32 | ~index), so
 // they are unique: an 8-pass MSB radix select finds the count-th largest key exactly, the survivors
-// are compacted into LDS and bitonic-sorted descending -> (score desc, index asc), deterministic.
+// are compacted and sorted descending -> (score desc, index asc), deterministic.
+//   k <= TOPK_LDS_MAX: survivors live in LDS (8 B per key, up to 128 KiB of the CU's 160) and are bitonic-sorted there
+//                      (256 threads up to 4096 keys, 1024 beyond);
+//   larger k ("no cap": every cell above the threshold, frontend.py:122 / visual_odometry.py:112 with top_k <= 0, or
+//   a cap above 16384 on a big frame): survivors are compacted into the caller's idx row and sorted IN PLACE in
+//   global memory, keys rebuilt from score[idx] — no scratch buffer in the ABI, any k up to n.
 // ---------------------------------------------------------------------------------------------
-constexpr int TOPK_MAX = 4096;
+constexpr int TOPK_SMALL_MAX = 4096;     // 256-thread workgroups up to here
+constexpr int TOPK_LDS_MAX = 16384;      // keys that fit the LDS path
 
 __device__ __forceinline__ unsigned long long topk_key(float s, int idx, float thr) {
   if (!(s > thr)) return 0ull;
@@ -191,83 +197,89 @@ __device__ __forceinline__ unsigned long long topk_key(float s, int idx, float t
   return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
 }
 
-__global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
-  // all LDS in the dynamic region (16-byte aligned base): [kpow] keys | prefix | hist[256] | 3 counters
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
-  const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
-  const float* sc = a.score + (size_t)b * n;
-  int kpow = 1;
-  while (kpow < a.k) kpow <<= 1;
-  unsigned long long& s_prefix = s_keys[kpow];
-  unsigned* hist = reinterpret_cast<unsigned*>(&s_keys[kpow + 2]);
+// Shared front half: count the candidates and, when there are more than k of them, find the k-th largest key.
+// hist: LDS [260] (256 bins + rank, ncand, fill, done); s_prefix: LDS.  Returns the selection threshold
+// (1: every candidate, ~0: nothing) and the number of selected keys through `count_out`.
+template <int NTHR>
+__device__ __forceinline__ unsigned long long topk_threshold(const float* sc, int n, int k, float thr, unsigned* hist,
+                                                             unsigned long long& s_prefix, unsigned& count_out) {
+  const int tid = threadIdx.x;
   unsigned& s_rank = hist[256];
   unsigned& s_ncand = hist[257];
-  unsigned& s_fill = hist[258];
   unsigned& s_done = hist[259];
-
   if (tid == 0) s_ncand = 0;
   __syncthreads();
   unsigned local = 0;
-  for (int e = tid; e < n; e += 256) local += (sc[e] > a.thr) ? 1u : 0u;
+  for (int e = tid; e < n; e += NTHR) local += (sc[e] > thr) ? 1u : 0u;
   atomicAdd(&s_ncand, local);
   __syncthreads();
   const unsigned ncand = s_ncand;
-  const unsigned count = min((unsigned)a.k, ncand);
-  if (tid == 0) a.count[b] = (int)count;
-
-  for (int e = tid; e < kpow; e += 256) s_keys[e] = 0ull;
-
-  unsigned long long thresh = ~0ull;   // nothing selected
-  if (ncand <= (unsigned)a.k) {
-    thresh = 1ull;                     // every candidate is selected (keys of candidates are non-zero): no rank to find
-  } else if (count > 0) {
-    if (tid == 0) { s_prefix = 0ull; s_rank = count; s_done = 0u; }
-    __syncthreads();
-    for (int pass = 7; pass >= 0; --pass) {
-      hist[tid] = 0;
-      __syncthreads();
-      const unsigned long long prefix = s_prefix;
-      const int shift = pass * 8;
-      const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
-      for (int e = tid; e < n; e += 256) {
-        const unsigned long long key = topk_key(sc[e], e, a.thr);
-        if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid < 64) {
-        // wave 0 locates the bin holding the rank-th largest key: lane l owns bins 4l..4l+3, a suffix sum over lanes
-        // gives the number of keys in higher bins (the serial 256-step scan this replaces was ~10 % of the kernel)
-        const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-        const unsigned mine = h0 + h1 + h2 + h3;
-        unsigned above = mine;                       // inclusive suffix sum over lanes >= tid
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned v = __shfl_down(above, o);
-          if (tid + o < 64) above += v;
-        }
-        above -= mine;                               // keys in bins of higher lanes
-        const unsigned rank = s_rank;
-        if (above < rank && rank <= above + mine) {  // exactly one lane: the rank-th key is in one of its 4 bins
-          unsigned cum = above;
-          int bin = 4 * tid + 3;
-          unsigned hb = h3;
-          if (cum + h3 < rank) { cum += h3; bin = 4 * tid + 2; hb = h2;
-            if (cum + h2 < rank) { cum += h2; bin = 4 * tid + 1; hb = h1;
-              if (cum + h1 < rank) { cum += h1; bin = 4 * tid; hb = h0; } } }
-          s_rank = rank - cum;
-          s_prefix = prefix | ((unsigned long long)bin << shift);
-          // every key of the chosen bin is selected: the remaining digits cannot change the set (keys are unique,
-          // so this is reached at the latest when the bin holds one key) -> stop refining
-          s_done = (rank - cum == hb) ? 1u : 0u;
-        }
-      }
-      __syncthreads();
-      if (s_done) break;
-    }
-    thresh = s_prefix;   // the count-th largest key
-  }
-  if (tid == 0) s_fill = 0;
+  const unsigned count = min((unsigned)k, ncand);
+  count_out = count;
+  if (ncand <= (unsigned)k) return 1ull;      // every candidate is selected (candidate keys are non-zero): no rank to find
+  if (count == 0) return ~0ull;
+  if (tid == 0) { s_prefix = 0ull; s_rank = count; s_done = 0u; }
   __syncthreads();
-  for (int e = tid; e < n; e += 256) {
+  for (int pass = 7; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    const int shift = pass * 8;
+    const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
+    for (int e = tid; e < n; e += NTHR) {
+      const unsigned long long key = topk_key(sc[e], e, thr);
+      if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // wave 0 locates the bin holding the rank-th largest key: lane l owns bins 4l..4l+3, a suffix sum over lanes
+      // gives the number of keys in higher bins (the serial 256-step scan this replaces was ~10 % of the kernel)
+      const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned above = mine;                       // inclusive suffix sum over lanes >= tid
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_down(above, o);
+        if (tid + o < 64) above += v;
+      }
+      above -= mine;                               // keys in bins of higher lanes
+      const unsigned rank = s_rank;
+      if (above < rank && rank <= above + mine) {  // exactly one lane: the rank-th key is in one of its 4 bins
+        unsigned cum = above;
+        int bin = 4 * tid + 3;
+        unsigned hb = h3;
+        if (cum + h3 < rank) { cum += h3; bin = 4 * tid + 2; hb = h2;
+          if (cum + h2 < rank) { cum += h2; bin = 4 * tid + 1; hb = h1;
+            if (cum + h1 < rank) { cum += h1; bin = 4 * tid; hb = h0; } } }
+        s_rank = rank - cum;
+        s_prefix = prefix | ((unsigned long long)bin << shift);
+        // every key of the chosen bin is selected: the remaining digits cannot change the set (keys are unique,
+        // so this is reached at the latest when the bin holds one key) -> stop refining
+        s_done = (rank - cum == hb) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+  return s_prefix;   // the count-th largest key
+}
+
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void topk_kernel(const TopkArgs a, const int kpow) {
+  // all LDS in the dynamic region (16-byte aligned base): [kpow] keys | prefix | (pad) | hist[256] | 4 counters
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+  const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
+  const float* sc = a.score + (size_t)b * n;
+  unsigned long long& s_prefix = s_keys[kpow];
+  unsigned* hist = reinterpret_cast<unsigned*>(&s_keys[kpow + 2]);
+  unsigned& s_fill = hist[258];
+
+  // kpow >= 2 always (launch_topk): the sort's first compare reads s_keys[0] and s_keys[1], both inside the key region
+  for (int e = tid; e < kpow; e += NTHR) s_keys[e] = 0ull;
+  unsigned count;
+  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count);
+  if (tid == 0) { a.count[b] = (int)count; s_fill = 0; }
+  __syncthreads();
+  for (int e = tid; e < n; e += NTHR) {
     const unsigned long long key = topk_key(sc[e], e, a.thr);
     if (key != 0ull && key >= thresh) {
       const unsigned slot = atomicAdd(&s_fill, 1u);
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
   while (ksort < (int)count) ksort <<= 1;
   for (int size = 2; size <= ksort; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (ksort >> 1); t += 256) {
+      for (int t = tid; t < (ksort >> 1); t += NTHR) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = ((lo & size) == 0);
@@ -290,20 +302,92 @@ __global__ __launch_bounds__(256) void topk_kernel(const TopkArgs a) {
       __syncthreads();
     }
   }
-  for (int e = tid; e < a.k; e += 256) {
-    const unsigned long long key = s_keys[e];
+  for (int e = tid; e < a.k; e += NTHR) {
     const bool ok = (unsigned)e < count;
+    const unsigned long long key = ok ? s_keys[e] : 0ull;
     const int idx = ok ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : -1;
     a.idx[(size_t)b * a.k + e] = idx;
     if (a.val) a.val[(size_t)b * a.k + e] = ok ? sc[idx] : 0.f;
   }
 }
 
+// Large k: the selected cells are compacted into the frame's idx row (arrival order) and sorted there.  The network is
+// the one-direction ("flip") form of the bitonic sort — every compare-exchange puts the larger key at the lower
+// position — so positions past `count` behave as minimal sentinels without existing: a pair whose upper position is
+// >= count is simply skipped, and any count (not only powers of two) sorts in place.
+__global__ __launch_bounds__(1024) void topk_global_kernel(const TopkArgs a) {
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned hist[260];
+  constexpr int NTHR = 1024;
+  const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
+  const float* sc = a.score + (size_t)b * n;
+  int32_t* idx = a.idx + (size_t)b * a.k;
+  unsigned& s_fill = hist[258];
+  unsigned count;
+  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count);
+  if (tid == 0) { a.count[b] = (int)count; s_fill = 0; }
+  __syncthreads();
+  for (int e = tid; e < n; e += NTHR) {
+    const unsigned long long key = topk_key(sc[e], e, a.thr);
+    if (key != 0ull && key >= thresh) {
+      const unsigned slot = atomicAdd(&s_fill, 1u);
+      if (slot < count) idx[slot] = e;
+    }
+  }
+  __syncthreads();       // global stores of this workgroup are visible to its other waves after the barrier
+  unsigned npow = 2;
+  while (npow < count) npow <<= 1;
+  for (unsigned size = 2; size <= npow; size <<= 1) {
+    // flip step: position i of the lower half of each block meets its mirror in the upper half
+    for (unsigned t = tid; t < (npow >> 1); t += NTHR) {
+      const unsigned blk = t / (size >> 1), off = t % (size >> 1);
+      const unsigned lo = blk * size + off, hi = blk * size + size - 1 - off;
+      if (hi < count) {
+        const int il = idx[lo], ih = idx[hi];
+        if (topk_key(sc[il], il, -INFINITY) < topk_key(sc[ih], ih, -INFINITY)) { idx[lo] = ih; idx[hi] = il; }
+      }
+    }
+    __syncthreads();
+    for (unsigned stride = size >> 2; stride > 0; stride >>= 1) {
+      for (unsigned t = tid; t < (npow >> 1); t += NTHR) {
+        const unsigned lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        if (hi < count) {
+          const int il = idx[lo], ih = idx[hi];
+          if (topk_key(sc[il], il, -INFINITY) < topk_key(sc[ih], ih, -INFINITY)) { idx[lo] = ih; idx[hi] = il; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < a.k; e += NTHR) {
+    const bool ok = (unsigned)e < count;
+    if (!ok) idx[e] = -1;
+    if (a.val) a.val[(size_t)b * a.k + e] = ok ? sc[idx[e]] : 0.f;
+  }
+}
+
 int launch_topk(const TopkArgs& a, hipStream_t s) {
-  if (a.k < 1 || a.k > TOPK_MAX || a.n < 1) return -1300;
-  int kpow = 1;
-  while (kpow < a.k) kpow <<= 1;
-  hipLaunchKernelGGL(topk_kernel, dim3(a.B), dim3(256), (size_t)kpow * 8 + 16 + 260 * 4, s, a);
+  if (a.k < 1 || a.n < 1) return -1300;
+  const int keff = a.k < a.n ? a.k : a.n;      // more than n keys can never be selected
+  if (keff > TOPK_LDS_MAX) {
+    hipLaunchKernelGGL(topk_global_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    return (int)hipGetLastError();
+  }
+  int kpow = 2;                                 // >= 2: the sort network always touches two key slots
+  while (kpow < keff) kpow <<= 1;
+  const size_t lds = (size_t)kpow * 8 + 16 + 260 * 4;
+  if (keff <= TOPK_SMALL_MAX) {
+    hipLaunchKernelGGL(topk_kernel<256>, dim3(a.B), dim3(256), lds, s, a, kpow);
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(topk_kernel<1024>, dim3(a.B), dim3(1024), lds, s, a, kpow);
+  }
   return (int)hipGetLastError();
 }
 

@@ -93,9 +93,29 @@ def tiny_factory(config, n_classes, to_mcu=False, to_export=False, v3=False):
 # ---------------------------------------------------------------------------------------------
 # parameter containers: same attribute tree as the reference => same state_dict keys
 # ---------------------------------------------------------------------------------------------
+# Weight-change tracking.  The engine re-uploads the state dict whenever a tensor of it changed (in-place writes bump
+# ``_version``) or was replaced.  Rebuilding ``state_dict()`` on every call to see that cost ~185 us per call — as much
+# as a whole single-frame step on the GPU — so the model keeps the list of its tensors and only walks the module tree
+# again after something could have REPLACED a tensor: a parameter / buffer registration anywhere (global torch hooks),
+# or an ``_apply`` (.to / .cuda / .float ...) on any holder.  Both bump this epoch.
+_STRUCT_EPOCH = [0]
+
+
+def _bump_epoch(*_a, **_k):
+    _STRUCT_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+
+
 class _Holder(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover - guards against silent torch execution
         raise RuntimeError("parameter holder: the arithmetic runs in libkp2d_hip.so via the parent model")
+
+    def _apply(self, fn, *a, **k):
+        _bump_epoch()
+        return super()._apply(fn, *a, **k)
 
 
 class _CBR(_Holder):
@@ -364,10 +384,34 @@ class _KP2DTinyBase(nn.Module):
     def _check_built(self):
         pass
 
-    def _weights_signature(self):
-        return tuple((id(t), t._version) for t in self.state_dict(keep_vars=True).values())
+    def _apply(self, fn, *a, **k):
+        _bump_epoch()
+        return super()._apply(fn, *a, **k)
 
-    def _get_engine(self, device: torch.device) -> _Engine:
+    def load_state_dict(self, *a, **k):
+        _bump_epoch()                      # assign=True replaces tensors without any registration hook
+        return super().load_state_dict(*a, **k)
+
+    def _weights_signature(self):
+        cache = self.__dict__.get("_sig_cache")
+        if cache is None or cache[0] != _STRUCT_EPOCH[0]:
+            cache = (_STRUCT_EPOCH[0], list(self.state_dict(keep_vars=True).values()))
+            self.__dict__["_sig_cache"] = cache
+        return tuple((id(t), t._version) for t in cache[1])
+
+    def _warn_if_training_semantics_expected(self):
+        """The reference runs BatchNorm on batch statistics and applies Dropout2d while its sub-modules are in training
+        mode (a caller that skips ``model.eval()``); this build implements inference only (running statistics, no
+        dropout), so say so once instead of silently returning eval-mode numbers."""
+        if self.backbone.training and not self.__dict__.get("_warned_train"):
+            import warnings
+            warnings.warn("KP2DTiny (MI355X build) implements inference semantics only: BatchNorm uses its running "
+                          "statistics and Dropout2d is inactive even though the sub-modules are in training mode. "
+                          "Call model.eval() (the reference does: demo.py, eval_multitask.py).", RuntimeWarning,
+                          stacklevel=3)
+            self.__dict__["_warned_train"] = True
+
+    def _get_engine(self, device: torch.device, need_weights: bool = True) -> _Engine:
         if device.type != "cuda":
             raise RuntimeError(
                 "KP2DTiny (MI355X build) runs on a HIP device only: move the model and the input to 'cuda'. "
@@ -378,6 +422,8 @@ class _KP2DTinyBase(nn.Module):
         if eng is None or eng.device != idx:
             eng = _Engine(self._engine_config(idx))
             self.__dict__["_engine"] = eng
+        if not need_weights:               # post_processing: kp2d_post reads the configuration only
+            return eng
         sig = self._weights_signature()
         if eng.signature != sig:
             eng.upload(self.state_dict())
@@ -434,6 +480,7 @@ class _KP2DTinyBase(nn.Module):
         if x.dtype != torch.float32:
             raise TypeError("input must be float32")
         eng = self._get_engine(x.device)
+        self._warn_if_training_semantics_expected()
         x = x.contiguous()
         B, _, H, W = x.shape
         q = 2 * self.cell    # the segmentation head pools the cell grid once more
@@ -465,7 +512,7 @@ class _KP2DTinyBase(nn.Module):
         score, shift, feat = out["score"], out["coord"], out["feat"]
         if score.device.type != "cuda":
             raise RuntimeError("post_processing runs on the HIP device only")
-        eng = self._get_engine(score.device)
+        eng = self._get_engine(score.device, need_weights=False)
         score, shift, feat = score.contiguous(), shift.contiguous(), feat.contiguous()
         B, _, Hc, Wc = score.shape
         dev = score.device
@@ -536,6 +583,7 @@ class _KP2DTinyBase(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
             raise ValueError(f"expected float32 [B,3,H,W] input, got {x.dtype} {tuple(x.shape)}")
         eng = self._get_engine(x.device)
+        self._warn_if_training_semantics_expected()
         x = x.contiguous()
         B, _, H, W = x.shape
         q = 2 * self.cell

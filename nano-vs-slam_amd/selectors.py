@@ -31,6 +31,8 @@ def select_topk(score: torch.Tensor, k: int, thr: float = float("-inf")):
     B = score.shape[0]
     s = score.reshape(B, -1).contiguous().float()
     n = s.shape[1]
+    if k < 1:
+        raise ValueError("k must be >= 1 (use k = number of cells for 'every cell above the threshold')")
     k = int(min(k, n))
     idx = torch.empty(B, k, dtype=torch.int32, device=s.device)
     val = torch.empty(B, k, dtype=torch.float32, device=s.device)
@@ -55,15 +57,22 @@ def gather_keypoints(coord: torch.Tensor, desc: torch.Tensor, idx: torch.Tensor)
     return pts, dsel
 
 
+def _cap(top_k: int, score: torch.Tensor) -> int:
+    """The reference's cap semantics (``if len(score) > top_k and top_k > 0``): top_k <= 0 means no cap."""
+    n = score[0].numel()
+    return n if top_k <= 0 else min(int(top_k), n)
+
+
 def select_keypoints(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, scale=None):
     """K1/K2 for a whole batch.  ``out`` is the dict returned by ``post_processing``.
 
     Returns a list (one entry per frame) of (pts [n,2], desc [n,C], idx [n]) device tensors, n <= top_k.
+    ``top_k <= 0`` keeps every cell above the threshold, as the reference does (visual_odometry.py:112).
     ``scale`` = (scale_x, scale_y) divides the coordinates as the VO front-end does when it resized
     the frame (evaluation/visual_odometry.py:119-121).
     """
     score, coord, feat = out["score"], out["coord"], out["feat"]
-    idx, _val, cnt = select_topk(score, top_k, nn_thresh)
+    idx, _val, cnt = select_topk(score, _cap(top_k, score), nn_thresh)
     pts, dsel = gather_keypoints(coord, feat, idx)
     counts = cnt.tolist()  # the only host sync: one int per frame
     res = []
@@ -80,7 +89,7 @@ def select_keypoints_host(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, 
     numpy arrays.  Three device-to-host copies for the whole batch (counts, padded points, padded descriptors) instead
     of two per frame."""
     score, coord, feat = out["score"], out["coord"], out["feat"]
-    idx, _val, cnt = select_topk(score, top_k, nn_thresh)
+    idx, _val, cnt = select_topk(score, _cap(top_k, score), nn_thresh)
     pts, dsel = gather_keypoints(coord, feat, idx)
     if scale is not None:
         pts = pts / torch.tensor([scale[0], scale[1]], device=pts.device, dtype=pts.dtype)

@@ -59,11 +59,13 @@ class KP2DtinyFrontend(object):
         out = self.net.post_processing(self.net.forward(img), H, W)
         score, seg = out["score"], out["seg"]
         if self.apply_semantic_filer:
-            # sample_segmentation=True: seg is the class at each cell; filtered classes never pass the threshold
+            # sample_segmentation=True: seg is the class at each cell.  Cells of a filtered class are EXCLUDED
+            # (frontend.py:112-116 ANDs the masks): -inf never passes "score > nn_thresh", whatever the threshold.
             banned = torch.isin(seg.view(1, -1), torch.as_tensor(self.classes_to_filter, device=seg.device))
-            score = torch.where(banned.view_as(score), torch.zeros_like(score), score)
+            score = torch.where(banned.view_as(score), torch.full_like(score, float("-inf")), score)
+        # top_k <= 0 is "no cap" in the reference (frontend.py:122): every cell above the threshold is kept
         k = self.top_k if self.top_k > 0 else score[0].numel()
-        idx, _val, cnt = select_topk(score, min(k, 4096), self.nn_thresh)
+        idx, _val, cnt = select_topk(score, k, self.nn_thresh)
         pts, dsel = gather_keypoints(out["coord"], out["feat"], idx)
         n = int(cnt[0])
         sel = idx[0, :n].long()

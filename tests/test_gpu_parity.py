@@ -200,10 +200,75 @@ def test_full_size_properties():
         assert (val[b, 1:n] <= val[b, : n - 1]).all()
 
 
+def test_cfg4_full_size_properties():
+    """BASELINE configs[3] per-GPU share: V3 S_A (efficient self-attention on) at 480x640 x 32 frames, 19 classes.
+    This size runs in sub-batches under the 4 GiB workspace cap; results must not depend on that: batch permutation
+    and explicit sub-batch sizes give bit-identical outputs, and frame 0 equals the reference fixture v3_SA_480x640."""
+    meta, z = load_golden("v3_SA_480x640")
+    cfg, sd, x0 = golden_inputs(meta)
+    model, _ = product_model("S_A", True, 19)
+    B, H, W = 32, 480, 640
+    xs = synthetic_frames(B, H, W, seed=11)
+    xs[0] = x0[0]                                  # frame 0 = the fixture's frame
+    x = torch.from_numpy(xs).to(DEV)
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in model(x).items()}
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+        b = model(x[perm].contiguous())
+        for k in a:
+            assert torch.equal(a[k][perm], b[k]), k
+        del b
+        eng = model._engine
+        for frames in (3, 16):
+            eng.lib.kp2d_set_chunk_frames(eng.handle, frames)
+            eng._ws = None
+            c = model(x)
+            for k in a:
+                assert torch.equal(a[k], c[k]), (k, frames)
+            del c
+        eng.lib.kp2d_set_chunk_frames(eng.handle, 0)
+        eng._ws = None
+    st = meta["dense_stride"]
+    assert float((a["score"][0:1].cpu() - torch.from_numpy(z["fwd_score"])).abs().max()) < TOL
+    assert float((a["coord"][0:1].cpu() - torch.from_numpy(z["fwd_shift"])).abs().max()) < TOL
+    assert float((a["vlad"][0:1].cpu() - torch.from_numpy(z["fwd_vlad"])).abs().max()) < 1e-5
+    assert float((a["feat"][0:1, :, ::st, ::st].cpu() - torch.from_numpy(z["fwd_feat"])).abs().max()) < TOL
+    assert float((a["seg"][0:1, :, ::st, ::st].cpu() - torch.from_numpy(z["fwd_seg"])).abs().max()) < TOL
+    assert torch.allclose(a["seg"].sum(1), torch.ones_like(a["seg"][:, 0]), atol=1e-5)      # V3 eval: probabilities
+    assert torch.isfinite(a["feat"]).all() and torch.allclose(a["vlad"].norm(dim=1), torch.ones(B, device=DEV), atol=1e-5)
+
+
+def test_full_dense_maps_against_oracle_at_headline_size():
+    """The fixtures hold a stride-4 subsample of the dense maps at 240x320; here EVERY pixel of feat / seg (and the
+    post-processed descriptors and class map) of two frames is compared with the CPU oracle."""
+    model, sd = product_model("S", False, 28)
+    H, W = 240, 320
+    x = synthetic_frames(2, H, W, seed=7)
+    cfg = orc.get_config("S")
+    ref = orc.forward(x, sd, cfg)
+    refp = orc.post_processing(ref, H, W, cfg)
+    for prec in ("f16x3", "fp32"):
+        model.set_precision(prec)
+        fwd, post, post_np = _run(model, x, H, W)
+        for k in ("score", "coord", "feat", "vlad", "seg"):
+            assert fwd[k].shape == ref[k].shape
+            assert np.max(np.abs(fwd[k] - ref[k])) < TOL, (prec, k)
+        assert np.max(np.abs(post_np["feat"] - refp["feat"])) < TOL
+        part = np.partition(ref["seg"], -2, axis=1)
+        clear = (part[:, -1] - part[:, -2]) > 1e-3
+        assert np.array_equal(post_np["seg"][:, 0][clear], refp["seg"][:, 0][clear])
+
+
 def test_topk_kernel_against_oracle_with_ties():
     from nano_vs_slam_amd.selectors import select_topk
     rng = np.random.default_rng(2)
-    for n, k, thr in [(4800, 1000, 0.7), (1200, 4000, 0.7), (19200, 4096, -np.inf), (300, 7, 0.5), (64, 64, 2.0)]:
+    # after a large-k call: k = 1 and k = 2 (the sort network's smallest cases: ADVICE r1, stale LDS next to one key slot);
+    # 4097..16384: the 1024-thread LDS path; above: the in-place global sort ("no cap" at 480x640 = 19200 cells);
+    # 76800 cells = a 960x1280 frame
+    for n, k, thr in [(4800, 1000, 0.7), (1200, 4000, 0.7), (19200, 4096, -np.inf), (300, 7, 0.5), (64, 64, 2.0),
+                      (4800, 1, 0.7), (4800, 1, -np.inf), (300, 2, 0.74), (1, 1, 0.5), (19200, 4097, 0.2),
+                      (19200, 10000, 0.7), (19200, 16384, -np.inf), (19200, 16385, -np.inf), (19200, 19200, 0.7),
+                      (19200, 19200, -np.inf), (76800, 76800, 0.7), (76800, 30000, -np.inf), (17000, 17000, 0.1)]:
         s = rng.random((3, n)).astype(np.float32)
         s[:, ::7] = np.float32(0.75)            # many exact ties: lowest index must win
         s[1] = 0.0                              # a frame with nothing above threshold
@@ -473,6 +538,76 @@ def test_vo_frontend_wrapper_matches_reference_contract():
     assert len(pts2) == keep.sum() == len(seg2) and not np.isin(seg2, [3, 7, 11]).any()
     assert sorted(seg2.tolist()) == sorted(cls[keep].tolist())
     assert keep.sum() < (sc > 0.7).sum()                           # the filter removed something
+    # a negative threshold must still exclude filtered classes (they are masked with -inf, not with 0)
+    fe2.nn_thresh = -1.0
+    pts3, _, seg3 = fe2.run(img)
+    assert len(pts3) == (~np.isin(cls, [3, 7, 11])).sum() and not np.isin(seg3, [3, 7, 11]).any()
+
+
+@pytest.mark.parametrize("top_k", [0, -1, 10000, 19200, 4000])
+def test_vo_selection_is_never_truncated(top_k):
+    """K1 at 480x640 (19200 cells): the reference keeps EVERY cell above the threshold when top_k <= 0 or when fewer
+    than top_k survive (src/visual_odometry/frontend.py:122, src/evaluation/visual_odometry.py:112).  A low threshold
+    makes thousands of cells pass, far beyond the 4096-key limit the selection kernel had in round 1."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "src"))
+    from visual_odometry.frontend import KP2DtinyFrontend
+    from nano_vs_slam_amd.selectors import select_keypoints
+    meta, z = load_golden("v2_S_480x640")
+    cfg, sd, x = golden_inputs(meta)
+    H, W = meta["H"], meta["W"]
+    thr = 0.3
+    ref_score = z["post_score"]
+    n_pass = int((ref_score > thr).sum())
+    assert n_pass > 4096                                            # the case is past the old cap
+    fe = KP2DtinyFrontend((H, W), None, nn_thresh=thr, device=DEV, debug=False, config="S", top_k=top_k, nClasses=28)
+    fe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    pts, feat, seg = fe.run(torch.from_numpy((x[0] + 1.0) / 2.0))
+    ridx, rpts, rdesc = orc.select_k1(ref_score, z["post_coord"], z["post_feat"], thr, top_k)
+    assert len(ridx) == (n_pass if top_k <= 0 else min(n_pass, top_k))
+    assert pts.shape == (len(ridx), 2) and feat.shape == (len(ridx), 32)
+    # same SET of cells: recover each returned keypoint's cell from its coordinates
+    with torch.no_grad():
+        out = fe.net.post_processing(fe.net(torch.from_numpy(x).to(DEV)), H, W)
+    sel = select_keypoints(out, thr, top_k)[0]
+    got = np.sort(sel[2].cpu().numpy())
+    flat = ref_score.reshape(-1)
+    bound = thr if (top_k <= 0 or n_pass <= top_k) else flat[ridx].min()
+    _same_set(got, ridx, flat, bound)
+    assert len(got) == len(pts)
+    order, rorder = np.lexsort((pts[:, 1], pts[:, 0])), np.lexsort((rpts[:, 1], rpts[:, 0]))
+    if len(np.setxor1d(got, ridx)) == 0:
+        assert np.max(np.abs(pts[order] - rpts[rorder])) < 1e-3 and np.max(np.abs(feat[order] - rdesc[rorder])) < TOL
+
+
+def test_large_weights_keep_the_split_pack_finite():
+    """A checkpoint weight of 40.0 (|w| * 2^11 is past the fp16 range): the f16x3 pack picks a smaller per-layer
+    power-of-two pre-scale instead of storing inf / -inf halves.  Must match the
+    oracle like any other weight set, in both modes; a non-finite weight is refused by name."""
+    from nano_vs_slam_amd._lib import Kp2dError
+    model, sd = product_model("S", False, 28)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    sd["backbone.conv2a.conv.weight"][3, 5, 1, 1] = 40.0
+    sd["seg_head.convs.8.weight"][2, 7, 0, 2] = -300.0
+    sd["desc_head.convB.weight"][17, 1, 2, 2] = 17.5
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = synthetic_frames(2, 48, 64, seed=4)
+    cfg = orc.get_config("S")
+    ref = orc.forward(x, sd, cfg)
+    for prec in ("f16x3", "fp32"):
+        model.set_precision(prec)
+        with torch.no_grad():
+            out = {k: v.cpu().numpy() for k, v in model(torch.from_numpy(x).to(DEV)).items()}
+        for k in ("score", "coord", "feat", "vlad", "seg"):
+            assert np.isfinite(out[k]).all(), (prec, k)
+            scale = max(1.0, float(np.abs(ref[k]).max()))
+            assert np.max(np.abs(out[k] - ref[k])) < TOL * scale, (prec, k, float(np.max(np.abs(out[k] - ref[k]))))
+    bad = dict(sd)
+    bad["loc_head.convDa.conv.weight"] = sd["loc_head.convDa.conv.weight"].copy()
+    bad["loc_head.convDa.conv.weight"][0, 0, 0, 0] = np.inf
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in bad.items()})
+    with pytest.raises(Kp2dError, match="loc_head.convDa"):
+        model(torch.from_numpy(x).to(DEV))
 
 
 def test_streams_views_and_coexisting_models():

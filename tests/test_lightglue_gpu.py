@@ -164,3 +164,54 @@ def test_two_view_pipeline_extractor_plus_matcher():
                       "view1": {"image_size": np.array([[160.0, 120.0]] * 2, np.float32)}}, sd, lg.get_config(conf))
     la, rla = m["log_assignment"].cpu().numpy(), ref["log_assignment"]
     assert np.max(np.abs(la - rla) / (1.0 + np.abs(rla))) < 5e-5
+
+
+def test_cfg5_two_view_pipeline_at_full_size():
+    """BASELINE configs[4]: KP2DTiny-S keypoints + LightGlue on 480x640 pairs, 1024 keypoints per view.  The extractor
+    half is pinned by the reference fixture v2_S_480x640 (frame 0 of view 0 is the fixture's frame: K3 indices and
+    sampled descriptors must be the reference's); the matcher half (parity unpinned) is checked
+    against the oracle on the extractor's outputs and through size-independent properties."""
+    from conftest import golden_inputs, load_golden, product_model, assert_topk_equivalent
+    from lightglue.lightglue import LightGlue  # noqa: F401  (the reference's import line resolves)
+    from lightglue.lightglue_configs import get_light_glue_config
+    from nano_vs_slam_amd.pipeline import two_view_match
+    meta, z = load_golden("v2_S_480x640")
+    cfg, ksd, x0 = golden_inputs(meta)
+    net, _ = product_model("S", False, 28)
+    conf = dict(get_light_glue_config("S"), filter_threshold=0.1)
+    sd = lg.seeded_state_dict(lg.get_config(conf))
+    matcher = product(conf, sd)
+    H, W, K = 480, 640, 1024
+    img0 = torch.from_numpy((x0 + 1.0) / 2.0).to(DEV)                     # the extractor applies .sub(0.5).mul(2)
+    shift = torch.roll(img0, shifts=(8, 12), dims=(2, 3))                  # view 1: the same scene, translated
+    g = torch.Generator(device=DEV).manual_seed(5)
+    other = torch.rand(1, 3, H, W, device=DEV, generator=g)
+    image0 = torch.cat([img0, other], 0)
+    image1 = torch.cat([shift, other], 0)                                  # pair 1 matches an image with itself
+    p0, p1, m = two_view_match(net, matcher, image0, image1, max_num_keypoints=K)
+    assert p0["keypoints"].shape == (2, K, 2) and p0["descriptors"].shape == (2, K, 32)
+    assert m["log_assignment"].shape == (2, K + 1, K + 1) and m["matches0"].shape == (2, K)
+    # extractor half against the reference fixture
+    assert_topk_equivalent(p0["indices"][0].cpu().numpy(), z["post_score"][0].reshape(-1), z["k3_idx"][0])
+    ref_desc = z["post_feat"][0].reshape(32, -1)
+    idx0 = p0["indices"][0].long().cpu().numpy()
+    assert np.max(np.abs(p0["descriptors"][0].cpu().numpy() - ref_desc[:, idx0].T)) < 2e-4
+    ref_pts = z["post_coord"][0].reshape(2, -1)
+    assert np.max(np.abs(p0["keypoints"][0].cpu().numpy() - ref_pts[:, idx0].T)) < 1e-3
+    # matcher half against the oracle on the same keypoints / descriptors
+    ref = lg.forward({"keypoints0": p0["keypoints"].cpu().numpy(), "keypoints1": p1["keypoints"].cpu().numpy(),
+                      "descriptors0": p0["descriptors"].cpu().numpy(), "descriptors1": p1["descriptors"].cpu().numpy(),
+                      "view0": {"image_size": np.array([[float(W), float(H)]] * 2, np.float32)},
+                      "view1": {"image_size": np.array([[float(W), float(H)]] * 2, np.float32)}}, sd, lg.get_config(conf))
+    la, rla = m["log_assignment"].cpu().numpy(), ref["log_assignment"]
+    assert np.max(np.abs(la - rla) / (1.0 + np.abs(rla))) < 1e-4
+    # properties: mutual one-to-one matches, sub-stochastic assignment, identical pair matches itself
+    m0, m1 = m["matches0"].cpu().numpy(), m["matches1"].cpu().numpy()
+    for b in range(2):
+        v = np.nonzero(m0[b] >= 0)[0]
+        assert np.array_equal(m1[b][m0[b][v]], v)
+        assert len(np.unique(m0[b][v])) == len(v)
+    P = np.exp(la[:, :-1, :-1])
+    assert P.sum(2).max() <= 1 + 1e-4 and P.sum(1).max() <= 1 + 1e-4
+    same = m0[1] >= 0
+    assert np.array_equal(m0[1][same], np.arange(K)[same])          # identical views: a keypoint can only match itself
