@@ -42,6 +42,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="frames per step over ALL ranks, split into contiguous shards (BASELINE cfg 3: 256 over 8 GPUs "
+                         "= 32 per GPU); overrides --batch")
+    ap.add_argument("--no-precision-modes", action="store_true",
+                    help="skip timing the other arithmetic mode (precision_modes in the JSON line)")
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--config", default="S")
@@ -180,7 +185,17 @@ def main():
     if world > 1:
         broadcast_model_weights(model, dev, src=0)   # the one RCCL collective of the job
 
-    B, H, W = args.batch, args.height, args.width
+    from nano_vs_slam_amd.sharding import shard_range
+    if args.global_batch > 0:
+        if args.global_batch < world:
+            raise SystemExit("--global-batch must be at least the number of ranks")
+        lo, hi = shard_range(args.global_batch, rank, world)      # contiguous frame shard of this rank
+        B = hi - lo
+        global_batch = args.global_batch
+    else:
+        B = args.batch
+        global_batch = world * B
+    H, W = args.height, args.width
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     x = torch.rand(B, 3, H, W, device=dev, generator=g) * 2.0 - 1.0   # synthetic frames generated in HBM
 
@@ -196,22 +211,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def timed(precision):
+        """W untimed + K timed steps in one arithmetic mode; seconds for the K steps, MAX over ranks."""
+        model.set_precision(precision)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dt_ = time.perf_counter() - t0
+        t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # both arithmetic modes are driver-visible: the headline one (--precision) is `value`; the other is timed the same
+    # way (same K, W, barriers) and reported beside it in `precision_modes`
+    other = "fp32" if args.precision == "f16x3" else "f16x3"
+    modes = {}
+    if not args.no_precision_modes:
+        modes[other] = timed(other)
+    dt = timed(args.precision)
+    modes[args.precision] = dt
 
     if rank == 0:
-        frames = world * B * args.steps
+        frames = global_batch * args.steps
         fps = frames / dt
         with torch.no_grad():
             agg = kernel_profile(model, x, H, W, args.profile_steps)
@@ -261,10 +288,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade)" if args.precision == "f16x3" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"KP2DTiny-{args.config}{'-V3' if args.v3 else ''} {H}x{W}, batch {B}/GPU, "
+            "config": {"workload": f"KP2DTiny-{args.config}{'-V3' if args.v3 else ''} {H}x{W}, batch {B}/GPU"
+                                   f"{' (rank 0 shard of ' + str(global_batch) + ')' if args.global_batch > 0 else ''}, "
                                    f"all heads (score/loc/desc/seg/NetVLAD) + post_processing + top-{args.top_k} selection",
-                       "global_batch": world * B, "frame_shards": world, "n_classes": args.n_classes},
+                       "global_batch": global_batch, "frame_shards": world, "n_classes": args.n_classes},
             "roofline": roof,
+            "precision_modes": {k: {"value": round(frames / v, 1), "unit": "frames/s",
+                                    "ms_per_step": round(v / args.steps * 1e3, 3),
+                                    "arithmetic": ("split-fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulate"
+                                                   if k == "f16x3" else "exact fp32 on v_mfma_f32_32x32x2_f32")}
+                                for k, v in sorted(modes.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, sd_np)

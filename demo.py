@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from src.kp2dtiny.models.kp2dtiny import tiny_factory
-from nano_vs_slam_amd.pipeline import inference
+from nano_vs_slam_amd.pipeline import FrameStream, inference
 
 
 def main():
@@ -41,10 +41,15 @@ def main():
     n_kp = []
     pts, feat, out = inference(model, frame, new_size, device=a.device)      # warm-up
     torch.cuda.synchronize()
+    # the reference calls inference() once per video frame (evaluation/visual_odometry.py:409-495); FrameStream is that
+    # same step replayed as a HIP graph, with the next frame's upload overlapping the current frame's kernels
+    def video(n, f):
+        for _ in range(n):
+            f = np.roll(f, 3, axis=1)                                         # a panning "video"
+            yield f
+    fs = FrameStream(model, frame.shape[:2], new_size, device=a.device)
     t0 = time.perf_counter()
-    for _ in range(a.frames):
-        frame = np.roll(frame, 3, axis=1)                                     # a panning "video"
-        pts, feat, out = inference(model, frame, new_size, device=a.device)
+    for pts, feat, out in fs.map(video(a.frames, frame)):
         n_kp.append(len(pts))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -1295,7 +1295,7 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
   if (!score || !idx || !count) return fail(KP2D_ERR_ARG, "null argument");
   if (B < 1 || n < 1) return fail(KP2D_ERR_ARG, "empty score map (B=%d, n=%d)", B, n);
   if (k < 1) return fail(KP2D_ERR_ARG, "k must be >= 1 (pass k = n for \"every cell above the threshold\")");
-  DeviceGuard guard(score);
+  DeviceGuard guard(score, (hipStream_t)stream);
   TopkArgs a{score, B, n, k, thr, idx, val, count};
   int e = launch_topk(a, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "topk kernel: %d", e);
@@ -1305,7 +1305,7 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
 int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
                           float* pts, float* dsel, void* stream) {
   if (!coord || !desc || !idx || !pts || !dsel) return fail(KP2D_ERR_ARG, "null argument");
-  DeviceGuard guard(coord);
+  DeviceGuard guard(coord, (hipStream_t)stream);
   GatherArgs a{coord, desc, idx, pts, dsel, B, C, n, k};
   int e = launch_gather(a, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "gather kernel: %d", e);
@@ -1314,7 +1314,7 @@ int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* 
 
 int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int H, int W, void* stream) {
   if (!frames || !x || B < 1 || Hs < 1 || Ws < 1 || H < 1 || W < 1) return fail(KP2D_ERR_ARG, "bad preprocess arguments");
-  DeviceGuard guard(frames);
+  DeviceGuard guard(frames, (hipStream_t)stream);
   int e = launch_preprocess(frames, x, B, Hs, Ws, H, W, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "preprocess kernel: %d", e);
   return KP2D_OK;
@@ -1326,7 +1326,7 @@ int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, 
   if (!d0 || !n0 || !d1 || !n1 || !nn_idx || !nn_dist || !nn_dist2 || !match_q || !match_d || !scratch)
     return fail(KP2D_ERR_ARG, "null argument");
   if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
-  DeviceGuard guard(d0);
+  DeviceGuard guard(d0, (hipStream_t)stream);
   MatchArgs a{d0, d1, n0, n1, B, max0, max1, C, ratio, nn_idx, nn_dist, nn_dist2,
               reinterpret_cast<unsigned long long*>(scratch), match_q, match_d};
   int e = launch_match(a, (hipStream_t)stream);

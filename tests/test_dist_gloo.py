@@ -54,3 +54,47 @@ def test_broadcast_and_gather_world2_ragged():
     r = _run(7)
     assert all(v[0] and v[1] for v in r.values())
     assert sorted(v[2] for v in r.values()) == [3, 4]
+
+
+class _FakeModel:
+    """Duck-typed stand-in for the model's packed-weight exchange (packed_weights / load_packed_weights), so that
+    ``broadcast_model_weights`` itself — the entry point bench.py and the entry scripts call — runs on CPU ranks."""
+
+    def __init__(self, rank):
+        self.blob = (torch.arange(70001, dtype=torch.int64) * 7 % 251).to(torch.uint8) if rank == 0 else None
+        self.loaded = None
+
+    def packed_weights(self, device):
+        return self.blob.to(device)
+
+    def load_packed_weights(self, buf):
+        self.loaded = buf.clone()
+
+
+def _worker_model(rank, world, port, ret):
+    from nano_vs_slam_amd.sharding import broadcast_model_weights
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _FakeModel(rank)
+        broadcast_model_weights(m, "cpu", src=0)
+        want = (torch.arange(70001, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+        ret[rank] = (m.loaded is None) if rank == 0 else bool(torch.equal(m.loaded, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_model_weights_world2():
+    """Only rank 0 owns weights; rank 1 imports exactly the broadcast bytes; rank 0 does not re-import its own."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_model, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_range_covers_cfg3():
+    """BASELINE cfg 3: 256 frames over 8 GPUs = 32 contiguous frames per rank; ragged totals stay contiguous."""
+    assert [shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    for n, w in [(7, 2), (100, 8), (5, 8)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

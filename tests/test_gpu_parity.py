@@ -375,6 +375,49 @@ def test_inference_front_end_matches_oracle():
     assert np.max(np.abs(feat[order] - rdesc[rorder])) < 1e-3
 
 
+@pytest.mark.parametrize("src_hw,new_size,top_k", [((64, 96), None, 50), ((120, 200), (64, 96), 4000), ((64, 96), (64, 96), 0)])
+def test_frame_stream_equals_inference_frame_by_frame(src_hw, new_size, top_k):
+    """FrameStream = inference() replayed as a HIP graph with overlapped uploads (the VO loop, one frame per call):
+    bit-identical keypoints / descriptors / dense outputs for every frame, more frames than slots, and a weight update
+    in mid-stream takes effect without a recapture."""
+    from nano_vs_slam_amd.pipeline import FrameStream, inference
+    model, sd = product_model("S", False, 28)
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (*src_hw, 3), dtype=np.uint8) for _ in range(7)]
+    want = []
+    for f in frames:
+        pts, feat, out = inference(model, f, new_size, nn_thresh=0.5, top_k=top_k)
+        want.append((pts, feat, out["score"].clone(), out["seg"].clone()))
+    fs = FrameStream(model, src_hw, new_size, nn_thresh=0.5, top_k=top_k, device=DEV)
+    got = []
+    for pts, feat, out in fs.map(frames):
+        got.append((pts, feat, out["score"].clone(), out["seg"].clone()))
+    assert len(got) == len(want)
+    for (p0, f0, s0, g0), (p1, f1, s1, g1) in zip(want, got):
+        assert np.array_equal(p0, p1) and np.array_equal(f0, f1)
+        assert torch.equal(s0, s1) and torch.equal(g0, g1)
+    assert len(want[0][0]) > 0
+    with pytest.raises(RuntimeError):
+        fs.result()                                                   # nothing in flight
+    fs.submit(frames[0]); fs.submit(frames[1])
+    with pytest.raises(RuntimeError):
+        fs.submit(frames[2])                                          # both slots busy
+    fs.result(); fs.result()
+    # new weights: same graphs, new numbers
+    with torch.no_grad():
+        model.score_head.convDb.bias.add_(0.3)
+    p_new, f_new, _ = inference(model, frames[3], new_size, nn_thresh=0.5, top_k=top_k)
+    fs.submit(frames[3])
+    p_fs, f_fs, _ = fs.result()
+    assert np.array_equal(p_new, p_fs) and np.array_equal(f_new, f_fs) and len(p_new) != len(want[3][0])
+    # the other arithmetic mode: recaptured transparently
+    model.set_precision("fp32")
+    p_new, f_new, _ = inference(model, frames[4], new_size, nn_thresh=0.5, top_k=top_k)
+    fs.submit(frames[4])
+    p_fs, f_fs, _ = fs.result()
+    assert np.array_equal(p_new, p_fs) and np.array_equal(f_new, f_fs)
+
+
 def test_descriptor_matching_against_oracle():
     """kp2d_match_descriptors vs the restated BfFeatureMatcher (knnMatch k=2 + goodMatchesOneToOne)."""
     from nano_vs_slam_amd.matching import bf_match, match_descriptors
