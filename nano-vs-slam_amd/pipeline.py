@@ -12,6 +12,7 @@ Differences, all on purpose:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -69,8 +70,8 @@ class FrameStream:
     bottleneck (0.59 ms per frame).  Here the whole step — kp2d_preprocess, forward, post_processing, threshold/top-k
     selection, gather and the copies of the selected rows to pinned host memory — is captured once per slot into a HIP
     graph over static buffers and replayed with one call; frames go through ``slots`` (default 2) pinned staging buffers
-    so that the upload of frame n+1 (copy stream) and the caller's work on frame n-1's keypoints run while frame n
-    computes.  Same results as ``inference()``, bit for bit (same kernels, same order).
+    that the preprocess kernel reads in place, so the host's staging of frame n+1 and the caller's work on frame n-1's
+    keypoints run while frame n computes.  Same results as ``inference()``, bit for bit (same kernels, same order).
 
         fs = FrameStream(net, (Hs, Ws), new_size=(240, 320))
         for pts, feat, out in fs.map(frames): ...          # or fs.submit(frame) ... fs.result()
@@ -94,7 +95,12 @@ class FrameStream:
         self.copy_stream = torch.cuda.Stream(self.dev)
         self.compute_stream = torch.cuda.Stream(self.dev)
         self.pin_in = [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
-        self.dev_in = [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
+        self._pin_np = [p.numpy() for p in self.pin_in]
+        # the preprocess kernel reads the frame straight out of the pinned slot (device-visible host memory: 230 KB over
+        # PCIe inside the graph) instead of a separate H2D copy + event + cross-stream wait per frame
+        self.zero_copy = os.environ.get("KP2D_FS_ZERO_COPY", "1") != "0"
+        self.dev_in = (self.pin_in if self.zero_copy else
+                       [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)])
         self.ev_up = [torch.cuda.Event() for _ in range(self.slots)]
         self.ev_done = [torch.cuda.Event() for _ in range(self.slots)]
         self.graphs, self.outs, self.host = [], [], []
@@ -155,15 +161,20 @@ class FrameStream:
             self._sig = self.net._weights_signature()
         s = self._next
         self._next = (s + 1) % self.slots
-        t = frame if torch.is_tensor(frame) else torch.from_numpy(np.ascontiguousarray(frame))
-        if t.dtype != torch.uint8 or tuple(t.shape) != tuple(self.pin_in[s].shape[1:]):
+        f = frame.numpy() if torch.is_tensor(frame) else np.asarray(frame)
+        if f.dtype != np.uint8 or tuple(f.shape) != tuple(self.pin_in[s].shape[1:]):
             raise ValueError(f"expected a uint8 frame of shape {tuple(self.pin_in[s].shape[1:])}")
-        self.pin_in[s][0].copy_(t)
-        with torch.cuda.stream(self.copy_stream):
-            self.dev_in[s].copy_(self.pin_in[s], non_blocking=True)
-            self.ev_up[s].record(self.copy_stream)
+        # plain memcpy into the pinned slot.  NOT torch's copy_: for a 230 KB tensor it fans out over the intra-op
+        # thread pool, and on a box whose cgroup grants fewer CPUs than it shows that burns the CPU quota — measured
+        # as a 90 ms stall every ~20 frames (mean 4.6 ms per frame against a 0.42 ms median)
+        np.copyto(self._pin_np[s][0], f)
+        if not self.zero_copy:
+            with torch.cuda.stream(self.copy_stream):
+                self.dev_in[s].copy_(self.pin_in[s], non_blocking=True)
+                self.ev_up[s].record(self.copy_stream)
         with torch.cuda.stream(self.compute_stream):
-            self.compute_stream.wait_event(self.ev_up[s])
+            if not self.zero_copy:
+                self.compute_stream.wait_event(self.ev_up[s])
             self.graphs[s].replay()
             self.ev_done[s].record(self.compute_stream)
         self._pending.append(s)
