@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkp2d_hip.so")
+# KP2D_LIB: another build of the SAME library (kernel A/B timing on one box: tools/ab_variants.sh); never a fallback
+LIB_PATH = os.environ.get("KP2D_LIB") or os.path.join(_HERE, "csrc", "libkp2d_hip.so")
 
 KP2D_FWD_EVAL = 1
 KP2D_FWD_ONLY_ENCODER = 2

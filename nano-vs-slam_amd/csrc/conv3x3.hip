@@ -42,21 +42,6 @@
 
 namespace kp2d {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// fp32 pair -> (hi, lo) fp16 pairs with hi = rn(x), lo = rn(x - hi): v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (reads the
-// fp16 half directly: x - float(hi) without a conversion), v_cvt_pk_f16_f32 (4 instructions per two values)
-__device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
-  const f32x2 v = {x, y};
-  hi = __builtin_convertvector(v, f16x2);
-  f32x2 r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hi), "v"(x));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hi), "v"(y));
-  lo = __builtin_convertvector(r, f16x2);
-}
-
 constexpr int IN_ROWS = 18;
 // LDS row pitch of the input image in pixels.  32-channel tiles (NT = 1) use 20 so that image + weight slab is
 // 51.8 KB and THREE workgroups fit a CU (160 registers per thread allow it); the 64-channel tiles use 24.
@@ -214,9 +199,7 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
     for (int it = 0; it < IN_IT; ++it) {
       if (IN_G % 256 != 0 && tid + 256 * it >= IN_G) continue;
       const float4 v = rin[it];
-      if (PREC == 0 || a.in_s16) {
-        // fp32 operands, or a producer that already wrote [16 hi | 16 lo] fp16 blocks (conv_common.h):
-        // the 64-byte block IS the LDS row
+      if (PREC == 0) {
         *reinterpret_cast<float4*>(&s_in[st_lds[it] + st_q4]) = v;
       } else {
         // pixel row (80 B): [16 x fp16 hi][16 x fp16 lo][pad]; conversions saturate at the fp16 range
@@ -315,7 +298,24 @@ __global__ __launch_bounds__(256, ((NT == 1 || WST > 1) && KP2D_PITCH_NT1 < 24) 
 
   constexpr int EPI_ROUNDS = (WST > 1 && NT == 2) ? 2 : 1;
   constexpr bool EPI_GELU = TAPS == 1;
+  // accumulator layout of the 32x32 MFMA tiles (conv_epilogue.inc): lane (i, h), M-tile m, register r
+#define EPI_NM 2
+#define EPI_NN NT
+#define EPI_R 16
+#define EPI_ACC(m, n, r) acc[m][n][r]
+#define EPI_CH(n) ((n) * 32 + i)
+#define EPI_ROW(m, r) (wave * 4 + 2 * (m) + (((r) >> 1) & 1))
+#define EPI_COL(m, r) (2 * h + 4 * ((r) >> 2) + ((r) & 1))
+#define EPI_THREADS 256
 #include "conv_epilogue.inc"
+#undef EPI_THREADS
+#undef EPI_NM
+#undef EPI_NN
+#undef EPI_R
+#undef EPI_ACC
+#undef EPI_CH
+#undef EPI_ROW
+#undef EPI_COL
 }
 
 template <int KC, int NT, int TAPS, int PREC, int WST = 1>
@@ -349,8 +349,7 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   const bool one = a.npad == 32 || a.ng32;
   if (a.prec == 1) {
     if (kc != 16) return -1003;
-    static const bool wst3 = !(getenv("KP2D_WST") && getenv("KP2D_WST")[0] == '1');
-    if (a.taps == 9) return one ? launch_t<16, 1, 9, 1>(a, s) : (wst3 ? launch_t<16, 2, 9, 1, 3>(a, s) : launch_t<16, 2, 9, 1>(a, s));
+    if (a.taps == 9) return launch_conv3x3_f16x3(a, s);      // conv3x3_f16.hip
     if (a.taps == 1) return one ? launch_t<16, 1, 1, 1>(a, s) : launch_t<16, 2, 1, 1>(a, s);
     return -1000;
   }
@@ -428,23 +427,8 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
       const float t = fmaf(acc[c], a.scale[c], a.shift[c]);     // uniform index: scalar loads
       acc[c] = fmaxf(t, t * slope);
     }
-    if (a.out_s16) {
-      // CO == 16: one S16 block = [16 hi halves][16 lo halves] (conv_common.h)
-      f16x8 hv[2], lv[2];
-#pragma unroll
-      for (int c = 0; c < CO; ++c) {
-        const _Float16 hi = (_Float16)acc[c];
-        hv[c >> 3][c & 7] = hi;
-        lv[c >> 3][c & 7] = (_Float16)(acc[c] - (float)hi);
-      }
-      s_o[threadIdx.x * 4 + 0] = __builtin_bit_cast(float4, hv[0]);
-      s_o[threadIdx.x * 4 + 1] = __builtin_bit_cast(float4, hv[1]);
-      s_o[threadIdx.x * 4 + 2] = __builtin_bit_cast(float4, lv[0]);
-      s_o[threadIdx.x * 4 + 3] = __builtin_bit_cast(float4, lv[1]);
-    } else {
 #pragma unroll
       for (int c = 0; c < CO; c += 4) s_o[threadIdx.x * 4 + c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-    }
   }
   // The 256 pixels of this workgroup are one contiguous 16 KiB run of the NHWC output: go through LDS so every
   // store instruction of a wave writes 1 KiB of consecutive bytes (per-thread 64-byte rows cost 1.6x the write
@@ -530,7 +514,7 @@ int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
   // 256 / (H W) + 2 frames
   if ((256 / ((size_t)a.H * a.W) + 2) * 3 * (size_t)a.H * a.W * sizeof(float) >= 0x7ffffff0u) return -1002;
   if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16>), dim3(grid), dim3(256), 0, s, a);
-  else if (a.cout % 16 == 0 && a.cout <= 256 && !a.out_s16)
+  else if (a.cout % 16 == 0 && a.cout <= 256)
     hipLaunchKernelGGL(conv1a_wide_kernel, dim3(grid), dim3(256), (size_t)29 * a.cout * sizeof(float), s, a);
   else return -1001;
   return (int)hipGetLastError();

@@ -1,0 +1,286 @@
+// 3x3 / stride 1 / pad 1 convolution in split-fp16 ("f16x3") arithmetic on v_mfma_f32_16x16x32_f16.
+//
+// Same operator, tiling and epilogue as conv3x3.hip (AnnotatedConvBnReLUModel, modules/base.py:14-46, and the
+// biased 3x3 convs of the heads), but the matrix products run on the 16x16x32 MFMA shape (at equal cycles per FLOP
+// the chip holds a higher clock on it than on 32x32x16: MI355X_MICROARCH.md "DVFS give-back" (7)) from planar,
+// conflict-free LDS images, with 32 accumulator registers per wave.
+//
+// K = 32 of one MFMA = two taps x 16 channels.  An fp32 operand is x = xh + xl (fp16 halves), a weight w = wh + wl:
+//   tap pair (t, t'):  [xl_t | xl_t'] . [wh_t | wh_t']  +  [xh_t | xh_t'] . [wl_t | wl_t']  +  [xh_t | xh_t'] . [wh_t | wh_t']
+//   single tap t:      [xh_t | xl_t ] . [wh_t | wh_t ]  +  [xh_t | xl_t ] . [wl_t | wl_t ]      (all four cross terms)
+// i.e. 3 MFMAs per two taps + 2 for the ninth: 14 per 16-channel chunk instead of 13.5 (3.7 % padding).
+// The packer stores the nine taps of a chunk in slot order {0,1,3,4,2,5,6,7,8} (kp2d_api.cpp pack()): slots (0,1),
+// (2,3), (6,7) are taps one pixel apart in x, slots (4,5) = taps (2,5) one row apart, slot 8 is the single.
+//
+// LDS images are planar and unpadded: input [hi plane | lo plane], each [18 rows][20 px][16 halves = 32 B]; weights
+// [wh plane | wl plane], each [slot][n][32 B].  A lane of an operand read is (row p = lane & 15, k-group g = lane >> 4):
+// it takes 16 B at (pixel or weight row) * 32 + 16 * (g & 1); the lanes g >= 2 read the second tap (+1 pixel, +1 row or
+// the next slot) or, for the single tap, the lo plane.  With a 20-pixel row pitch every ds_read_b128 of either operand is
+// bank-conflict free (the 80-byte padded rows of conv3x3.hip were two-way on the pixel operand), and the images are
+// 41.5 KB (32-channel tiles) / 59.9 KB (64-channel tiles) per workgroup.
+//
+// MFMA rows: pixel index p = 4q + r of a 2 x 8 pixel M-tile is (row (r >> 1) & 1, column 2q + (r & 1)), so the four
+// accumulator registers of a lane are again one 2x2 pixel block (register-local max-pool).  A wave owns tile rows
+// 4w .. 4w+3 (w = wave & 3) as four M-tiles and ONE 32-channel block (two N-tiles): 32 accumulator registers.
+// A 64-channel tile is a 512-thread workgroup (NH = 2): waves 4-7 own channels 32-63 of the same 16 x 16 pixels, all
+// eight waves stage the one input image (half the iterations each) — the 64-accumulator wave of the 256-thread form
+// spilled at the 168-register budget of three workgroups per CU; this one fits 128 (two 512-thread workgroups per CU,
+// four waves per SIMD), keeps all nine weight slots resident and so has two barriers per chunk instead of six.
+#include "conv_common.h"
+
+namespace kp2d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int F_ROWS = 18, F_PITCH = 20, F_PXB = 32;
+constexpr int F_LO = F_ROWS * F_PITCH * F_PXB;      // byte offset of the lo plane (11520)
+constexpr int F_W = 2 * F_LO;                       // weight planes start behind the two input planes
+
+__host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
+__host__ __device__ constexpr int tap_off(int t) { return ((t / 3) * F_PITCH + (t % 3)) * F_PXB; }
+}  // namespace
+
+template <int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const sm = reinterpret_cast<char*>(smem);
+  constexpr int NT = NH;                            // 32-channel blocks per workgroup (conv_epilogue.inc)
+  constexpr int N = NH * 32, NN = 2;
+  constexpr int THREADS = 256 * NH;
+  constexpr int WL = 9 * N * 32;                    // byte offset of the wl plane behind the wh plane
+  constexpr int KC = 16, Q = 4;
+
+  const int tid = threadIdx.x;
+  // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL: fp16 conversions that overflow clamp to +-65504
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+  const int lane = tid & 63;
+  const int wave = (tid >> 6) & 3;                  // pixel rows 4 wave .. 4 wave + 3
+  const int nh = tid >> 8;                          // 32-channel block of this wave
+  // XCD-aware tile order (conv3x3.hip): every XCD gets a contiguous run of tiles
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * TILE, x0 = tx * TILE;
+  const int H = a.H, W = a.W;
+  const int n0 = blockIdx.y * N;
+
+  f32x4 acc[4][NN];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operand read addresses (bytes from the start of LDS); M-tile, tap, N-tile and slot offsets are immediates
+  const int lg = lane >> 4, lp = lane & 15;     // k-group and operand row of this lane
+  const int a0 = ((wave * 4 + ((lp >> 1) & 1)) * F_PITCH + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
+  const int a_dx = a0 + (lg >> 1) * F_PXB;               // second tap one pixel to the right
+  const int a_dy = a0 + (lg >> 1) * F_PITCH * F_PXB;     // second tap one row down
+  const int a_s = a0 + (lg >> 1) * F_LO;                 // single tap: k-groups 2, 3 read the lo plane
+  const int b_s = F_W + (nh * 32 + lp) * 32 + 16 * (lg & 1);
+  const int b_p = b_s + (lg >> 1) * N * 32;              // second tap = next slot
+
+  const int nchunk = (a.cin + KC - 1) / KC;
+  const float* src0 = a.in0.p + (size_t)b * a.in0.bs + a.in0.o;
+  const float* src1 = a.in1.p + (size_t)b * a.in1.bs + a.in1.o;
+  const int c0 = a.in0.c;
+
+  // staging: as conv3x3.hip (granule = 4 channels of one halo pixel, MUBUF loads whose out-of-range offset returns the
+  // zero padding, next chunk prefetched into registers), except that the granules walk the 18 x 20 LDS image itself
+  // (columns 18, 19 are never loaded): granule gi = tid + 256 it lands at byte 8 gi of the hi plane, so the LDS side
+  // needs no per-iteration register, and the global side keeps ONE pixel index per iteration — the byte offset into
+  // either source is pix * pixel-stride (both are dense NHWC views: row stride = W * pixel stride, checked at launch)
+  constexpr int IN_G = F_ROWS * F_PITCH * Q;
+  constexpr int IN_IT = (IN_G + THREADS - 1) / THREADS;
+  constexpr int W_G = 9 * N * Q;                    // weight granules of a chunk
+  constexpr int W_IT = (W_G + THREADS - 1) / THREADS;
+  float4 rin[IN_IT], rw[W_IT];
+  const int st_q4 = 4 * (tid % Q);
+  constexpr int OOB = 0x7ffffff0;
+  int st_pix[IN_IT];
+#pragma unroll
+  for (int it = 0; it < IN_IT; ++it) {
+    const int gi = tid + THREADS * it;
+    const int hp = gi / Q;
+    const int py = hp / F_PITCH, px = hp - py * F_PITCH;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = gi < IN_G && px < F_ROWS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    st_pix[it] = ok ? gy * W + gx : -1;
+  }
+  const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;      // pixel strides in bytes
+  // weight granule gi = tid + THREADS it of a chunk: 16-byte quad q = gi & 3 of row gi >> 2 (row = slot * N + n);
+  // quads 0, 1 are the hi halves, 2, 3 the lo halves of the packed [16 hi | 16 lo] row
+  const int w_lds = F_W + (tid >> 2) * 32 + (tid & 1) * 16 + ((tid >> 1) & 1) * WL;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src0), 0, (int)((a.in0.bs - a.in0.o) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src1), 0, (int)((a.in1.bs - a.in1.o) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w + (size_t)blockIdx.y * nchunk * 9 * N * KC), 0, nchunk * 9 * N * KC * 4, 0x00020000);
+  const bool uniform = ((c0 | a.cin) & (KC - 1)) == 0;
+
+  auto prefetch_in = [&](int ch) {
+    if (uniform) {
+      // chunks never straddle the two sources and never run past cin (every S config)
+      const bool first = ch * KC < c0;
+      const int so = (first ? ch * KC : ch * KC - c0) * 4 + st_q4 * 4;
+      const int ps = first ? ps0 : ps1;
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it) {
+        int pix = st_pix[it];
+        asm volatile("" : "+v"(pix));      // keep ONE register per granule: the per-source products must not be hoisted
+        const int off = pix < 0 ? OOB : pix * ps + so;
+        rin[it] = __builtin_bit_cast(float4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
+                                                   : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+      }
+    } else {
+      // per-thread source / tail selection (channel counts that are not multiples of 16: the N configs)
+      const int c = ch * KC + st_q4;
+      const bool first = c < c0;
+      const int so = (first ? c : c - c0) * 4;
+      const bool cok = c < a.cin;
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it) {
+        int pix = st_pix[it];
+        asm volatile("" : "+v"(pix));
+        const bool pok = cok && pix >= 0;
+        const int o0 = (pok && first) ? pix * ps0 + so : OOB;
+        const int o1 = (pok && !first) ? pix * ps1 + so : OOB;
+        const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+        const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+        rin[it] = __builtin_bit_cast(float4, v0 | v1);      // the other one is all zeros
+      }
+    }
+  };
+  auto commit_in = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      if (it == IN_IT - 1 && IN_G % THREADS != 0 && tid + THREADS * it >= IN_G) continue;
+      const float4 v = rin[it];
+      f16x2 h0, h1, l0, l1;
+      split2(v.x, v.y, h0, l0);
+      split2(v.z, v.w, h1, l1);
+      *reinterpret_cast<f16x4*>(sm + tid * 8 + it * THREADS * 8) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<f16x4*>(sm + F_LO + tid * 8 + it * THREADS * 8) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+  };
+
+  auto prefetch_w = [&](int ch) {
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+      rw[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + THREADS * it) * 16, 0));
+  };
+  prefetch_in(0);
+  prefetch_w(0);
+
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();          // every wave is done reading the previous chunk's LDS images
+    commit_in();
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      if (it == W_IT - 1 && W_G % THREADS != 0 && tid + THREADS * it >= W_G) continue;
+      *reinterpret_cast<float4*>(sm + w_lds + it * (THREADS / 4) * 32) = rw[it];
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk) { prefetch_in(ch + 1); prefetch_w(ch + 1); }
+
+#pragma unroll
+    for (int slot = 0; slot < 9; slot += 2) {
+      const int t = slot_tap(slot);
+      const bool single = slot == 8;
+      const bool dy = slot == 4;
+      const int ab = (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(t);
+      const int bb = (single ? b_s : b_p) + slot * N * 32;
+      f16x8 bh[NN], bl[NN];
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        bh[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512);
+        bl[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512 + WL);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int mo = (2 * (m >> 1) * F_PITCH + 8 * (m & 1)) * F_PXB;
+        if (single) {
+          // k-groups 0, 1 carry xh, groups 2, 3 xl of the same tap: both weight halves see both operand halves
+          const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
+          }
+        } else {
+          const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+          const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + F_LO);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  constexpr int EPI_ROUNDS = 1;
+  constexpr bool EPI_GELU = false;
+  // accumulator layout of the 16x16 MFMA tiles (conv_epilogue.inc): lane (lp, lg), M-tile m, register r
+#define EPI_NM 4
+#define EPI_NN NN
+#define EPI_R 4
+#define EPI_ACC(m, n, r) acc[m][n][r]
+#define EPI_CH(n) (nh * 32 + (n) * 16 + lp)
+#define EPI_ROW(m, r) (wave * 4 + 2 * ((m) >> 1) + (((r) >> 1) & 1))
+#define EPI_COL(m, r) (8 * ((m) & 1) + 2 * lg + ((r) & 1))
+#define EPI_THREADS THREADS
+#include "conv_epilogue.inc"
+#undef EPI_THREADS
+#undef EPI_NM
+#undef EPI_NN
+#undef EPI_R
+#undef EPI_ACC
+#undef EPI_CH
+#undef EPI_ROW
+#undef EPI_COL
+}
+
+template <int NH>
+static int launch_f(const ConvArgs& a, hipStream_t s) {
+  constexpr int N = NH * 32;
+  size_t lds = (size_t)F_W + 2 * 9 * N * 32;
+  const size_t lds_out = (size_t)N * 257 * sizeof(float);
+  if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
+  const size_t lds_tile = (size_t)16 * 16 * N * sizeof(float);
+  if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int grid = a.tiles_x * a.tiles_y * a.B;
+  const int groups = a.npad / N;
+  if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
+  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH>), dim3(grid, groups), dim3(256 * NH), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
+  if (a.taps != 9 || a.prec != 1) return -1000;
+  // the staging addresses a source pixel as (y * W + x) * pixel stride
+  if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return -1004;
+  if ((long)a.H * a.W * (a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps) * 4 >= 0x7ffffff0L) return -1002;
+  if (a.npad != 32 && a.npad % 64 != 0) return -1000;
+  const bool one = a.npad == 32 || a.ng32;
+  return one ? launch_f<1>(a, s) : launch_f<2>(a, s);
+}
+
+}  // namespace kp2d

@@ -47,19 +47,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-// "S16" activation format (f16x3 mode): a pixel's channels in blocks of 16, each block 64 B =
-// [16 x fp16 hi][16 x fp16 lo] with hi = fp16(x), lo = fp16(x - hi) — the operand form the split-fp16 MFMA
-// consumes, written once by the producer instead of being re-derived by every consumer workgroup.
-// Lane pairs (even, odd channel) exchange halves so each lane still issues one 4-byte store per value:
-// the even lane stores the two hi halves, the odd lane the two lo halves.  Returns the dword to store and
-// the float-slot offset inside the pixel for channel `ch` (ch = this lane's channel).
-__device__ __forceinline__ unsigned s16_pair(float v, int lane_odd) {
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)(v - (float)hi);
-  const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-  const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
-  return lane_odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 pair -> (hi, lo) fp16 pairs with hi = rn(x), lo = rn(x - hi): v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (reads the
+// fp16 half directly: x - float(hi) without a conversion), v_cvt_pk_f16_f32 (4 instructions per two values)
+__device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
+  const f32x2 v = {x, y};
+  hi = __builtin_convertvector(v, f16x2);
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hi), "v"(x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hi), "v"(y));
+  lo = __builtin_convertvector(r, f16x2);
 }
-__device__ __forceinline__ int s16_slot(int ch) { return ((ch >> 4) << 4) + ((ch & 1) << 3) + ((ch & 15) >> 1); }
 
 }  // namespace kp2d

@@ -67,8 +67,6 @@ struct ConvPack {
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
   size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows of w * 2^e, scale * 2^-e (pack())
   size_t w16n_off = 0;                        // the same rows in 32-channel groups (npad >= 64): small-grid launches
-  size_t w16s_off = 0;                        // same rows, staged order [chunk][dy][dx][n] + quad swizzle (conv_s16.hip)
-  bool s16_capable() const { return kind == 0 && (cin % 16) == 0; }
   size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
   size_t w16_floats() const { return (size_t)((cin + 15) / 16) * taps * npad * 16; }
 };
@@ -121,7 +119,6 @@ struct Act {
   size_t off = 0, bytes = 0;
   int C = 0, H = 0, W = 0;
   int PS = 0, CO = 0;  // channel-slice view of a wider tensor: pixel stride (0 = C) and first channel; bytes = 0 (not owned)
-  bool s16 = false;   // pre-split [16 hi | 16 lo] fp16 blocks (conv_common.h) instead of fp32; same byte size
 };
 
 }  // namespace
@@ -142,18 +139,11 @@ struct kp2d_model {
   bool finalized = false;
   int chunk_frames = 0;
   int precision = KP2D_PREC_F16X3;
-  bool s16_ok = false;    // every activation width is a multiple of 16 -> pre-split activations + LDS-DMA conv
   std::map<uint64_t, size_t> plan_cache;
   int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
   std::vector<hipStream_t> lane_streams;
   std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
-  bool use_dma = false;   // KP2D_DMA=1: run S16 layers on the LDS-DMA kernel (conv_s16.hip) instead of the
-                          // register-staged one.  Measured round 1: 12.7k vs 14.0k frames/s, so it is opt-in
-                          // until its pipeline is deeper.
-  bool no_s16 = true;     // KP2D_S16=1: pre-split (S16) activations between conv layers in f16x3 mode.  Measured
-                          // round 1: the producer-side split costs more in the exposed epilogue than it saves in
-                          // the (hidden) staging conversion: 14.7k vs 15.5k frames/s, so fp32 activations stay default.
   bool profiling = false;
   bool small_grid_ng32 = !(getenv("KP2D_NG32") && getenv("KP2D_NG32")[0] == '0');   // KP2D_NG32=0: always 64-channel groups
   std::vector<ProfRec> prof;
@@ -370,7 +360,6 @@ int describe(kp2d_model* m) {
     c.w16_off = take(c.w16_floats());
     if (c.npad >= 64) c.w16n_off = take(c.w16_floats());
     c.sc16_off = take(c.npad);
-    if (c.s16_capable()) c.w16s_off = take(c.w16_floats());
   }
   for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
   if (has_vlad) {
@@ -520,23 +509,18 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
             wv *= wscale;
             const _Float16 hi = (_Float16)wv;
             const _Float16 lo = (_Float16)(wv - (float)hi);
-            const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + tap) * ng + n) * 32;   // in halves
+            // 3x3 layers: the nine taps of a chunk sit in slot order {0,1,3,4,2,5,6,7,8} (conv3x3_f16.hip pairs
+            // slots (0,1) (2,3) (4,5) (6,7) into one K = 32 MFMA each; slot 8 is the single)
+            static const int kSlot[9] = {0, 1, 4, 2, 3, 5, 6, 7, 8};
+            const int slot = c.kind == 0 ? kSlot[tap] : tap;
+            const size_t row = ((((size_t)grp * nchunk16 + chk) * c.taps + slot) * ng + n) * 32;   // in halves
             h16[row + kk] = hi;
             h16[row + 16 + kk] = lo;
             if (c.npad >= 64) {   // 32-channel groups of the same rows
               _Float16* n16 = reinterpret_cast<_Float16*>(&blob[c.w16n_off]);
-              const size_t rown = ((((size_t)(q / 32) * nchunk16 + chk) * c.taps + tap) * 32 + (q % 32)) * 32;
+              const size_t rown = ((((size_t)(q / 32) * nchunk16 + chk) * c.taps + slot) * 32 + (q % 32)) * 32;
               n16[rown + kk] = hi;
               n16[rown + 16 + kk] = lo;
-            }
-            if (c.s16_capable()) {
-              // conv_s16.hip: slab per (chunk, dy) = rows r = dx*ng + n; 16-byte quad j of a row
-              // (0: hi k0-7, 1: hi k8-15, 2: lo k0-7, 3: lo k8-15) is stored at position j ^ ((r >> 2) & 3)
-              _Float16* s16 = reinterpret_cast<_Float16*>(&blob[c.w16s_off]);
-              const int dy = tap / 3, dx = tap % 3, r = dx * ng + n, swz = (r >> 2) & 3;
-              const size_t rowb = ((((size_t)grp * nchunk16 + chk) * 3 + dy) * 3 * ng + r) * 32;
-              s16[rowb + (((kk >> 3) ^ swz) << 3) + (kk & 7)] = hi;
-              s16[rowb + (((2 + (kk >> 3)) ^ swz) << 3) + (kk & 7)] = lo;
             }
           }
         }
@@ -572,7 +556,6 @@ struct Plan {
   char* ws;
   Arena arena;
   bool dry = false;       // only size the arena
-  bool s16_mode = false;  // f16x3 + every channel count a multiple of 16: activations travel pre-split (S16)
   int B, H, W;
   int rc = KP2D_OK;
 
@@ -622,26 +605,20 @@ struct Plan {
     return s;
   }
   // core launch: sources already described
-  bool in_s16 = false;        // format of the sources / destinations of the NEXT conv_src call (set by callers)
-  int out_s16[2] = {0, 0};
   void conv_src(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
                 int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
     if (rc != KP2D_OK || dry) return;
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     ConvArgs a{};
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
-    a.out0_s16 = out_s16[0]; a.out1_s16 = out_s16[1];
     const bool split = m->precision == KP2D_PREC_F16X3;
-    if (in_s16 && !(split && c.s16_capable())) { rc = fail(KP2D_ERR_STATE, "%s: S16 input reached a layer without an S16 kernel", name.c_str()); return; }
-    const bool dma = in_s16 && m->use_dma;   // LDS-DMA kernel (opt-in); otherwise the register-staged kernel copies the S16 rows
-    a.in_s16 = in_s16 ? 1 : 0;
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
-    a.w = m->blob + (dma ? c.w16s_off : (split ? c.w16_off : c.w_off));
+    a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     // Small grids (a frame or two at a time): a 64-channel-group launch would leave most CUs idle and each of its
     // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
-    if (split && !dma && !in_s16 && c.npad >= 64 && m->small_grid_ng32 &&
+    if (split && c.npad >= 64 && m->small_grid_ng32 &&
         (long)a.tiles_x * a.tiles_y * B * (c.npad / 64) < 256) {
       a.w = m->blob + c.w16n_off;
       a.ng32 = 1;
@@ -653,12 +630,11 @@ struct Plan {
     a.act = act; a.store = store; a.nsplit = nsplit;
     if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
-    const char* fam = dma ? "conv3x3_s16dma" : split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
+    const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
                             : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
-    check(dma ? launch_conv3x3_s16(a, stream) : launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
+    check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
     prof_end();
-    out_s16[0] = out_s16[1] = 0;
   }
   // generic conv over dense NHWC activations: in1 may be null (no concat).  Channel slices via (c0, o0).
   void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
@@ -666,17 +642,12 @@ struct Plan {
     if (rc != KP2D_OK || dry) return;
     ConvSrc s0 = dense(ptr(in0), in0, c0, o0);
     ConvSrc s1 = in1 ? dense(ptr(*in1), *in1, in1->C, 0) : dense(ptr(in0), in0, 0, 0);
-    if (in1 && in1->s16 != in0.s16) { rc = fail(KP2D_ERR_STATE, "%s: concat of mixed activation formats", name.c_str()); return; }
-    in_s16 = in0.s16;
     conv_src(name, s0, s1, act, store, out0, os0, oo0, out1, os1, oo1, nsplit, Hc, Wc);
-    in_s16 = false;
   }
   // 1x1 conv -> NHWC activation
-  Act pw(const std::string& name, const Act& in, int act, int store = ST_NHWC, bool s16out = false) {
+  Act pw(const std::string& name, const Act& in, int act, int store = ST_NHWC) {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     Act out{};
-    const bool fmt = s16_mode && s16out;
-    out_s16[0] = out_s16[1] = fmt ? 1 : 0;
     if (store == ST_NHWC_POOL) {
       out = alloc(c.cout, in.H / 2, in.W / 2);
       conv(name, in, in.C, 0, nullptr, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, in.H, in.W);
@@ -684,8 +655,6 @@ struct Plan {
       out = alloc(c.cout, in.H, in.W);
       conv(name, in, in.C, 0, nullptr, act, ST_NHWC, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, in.H, in.W);
     }
-    out.s16 = fmt;
-    out_s16[0] = out_s16[1] = 0;
     return out;
   }
   Act layernorm(const std::string& prefix, const Act& in) {
@@ -700,7 +669,7 @@ struct Plan {
     return out;
   }
   // SegFormerAttentionModule.forward (modules/segformer.py:217-220); `pool` folds the following MaxPool2d(2,2)
-  Act attention_module(const std::string& p, const Act& x, bool pool, bool s16out) {
+  Act attention_module(const std::string& p, const Act& x, bool pool) {
     const int C = x.C, h = x.H, w = x.W;
     Act ln1 = layernorm(p + ".att.norm", x);
     Act q = pw(p + ".att.fn.to_q", ln1, ACT_NONE);
@@ -744,18 +713,16 @@ struct Plan {
     release(f0);
     Act f2 = pw(p + ".mff.fn.net.1.net.1", f1, ACT_GELU);
     release(f1);
-    Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC, s16out);
+    Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC);
     release(f2);
     return f3;
   }
   // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
-  Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr, bool s16out = true) {
+  Act cbr(const std::string& name, const Act& in0, const Act* in1, int store, Act* pooled = nullptr) {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
     const int act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
     const int Hc = in0.H, Wc = in0.W;
     Act out{};
-    const bool fmt = s16_mode && s16out;
-    out_s16[0] = out_s16[1] = fmt ? 1 : 0;
     if (store == ST_NHWC) {
       out = alloc(c.cout, Hc, Wc);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, Hc, Wc);
@@ -771,9 +738,6 @@ struct Plan {
       out = alloc(c.cout / 4, Hc * 2, Wc * 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
-    out.s16 = fmt;
-    if (pooled) pooled->s16 = fmt;
-    out_s16[0] = out_s16[1] = 0;
     return out;
   }
 };
@@ -797,13 +761,11 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Conv1aArgs a{};
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
     a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk;
-    a.out_s16 = P.s16_mode ? 1 : 0;
     const double px = (double)B * H * W;
     P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 27 * m->c1 * px, 4.0 * px * (3 + m->c1));
     P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
     P.prof_end();
   }
-  t1a.s16 = P.s16_mode;
   Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC);
   P.release(t1a);
   Act t2a = P.cbr("backbone.conv2a", p1, nullptr, ST_NHWC);
@@ -828,10 +790,10 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // serial latencies (0.42 -> 0.37 ms per frame); at 32 frames per launch the strided slice reads cost what the
   // fuller grid gains (20.43k vs 20.36k frames/s).
   const bool small_grid = (long)((Hc + 15) / 16) * ((Wc + 15) / 16) * P.B < 256;
-  const bool merged = merge_env && small_grid && !only_enc && !P.s16_mode && m->conv_index.count("heads.first");
+  const bool merged = merge_env && small_grid && !only_enc && m->conv_index.count("heads.first");
   Act mx{};
   if (merged) mx = P.cbr("heads.first", xb, nullptr, ST_NHWC);
-  auto first = [&](const std::string& name, bool s16out = true) -> Act {
+  auto first = [&](const std::string& name) -> Act {
     if (merged) {
       int o = 0;
       for (const auto& pt : m->convs[m->conv_index.at("heads.first")].parts) {
@@ -839,7 +801,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
         o += pt.second;
       }
     }
-    return P.cbr(name, xb, nullptr, ST_NHWC, nullptr, s16out);
+    return P.cbr(name, xb, nullptr, ST_NHWC);
   };
   // ---- score / location heads (heads.py:28-35; sigmoid/tanh kp2dtiny.py:574-575, :927-935) ----
   if (only_enc) {
@@ -858,21 +820,15 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act d1 = first("desc_head.convA");
     const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
     Act d2 = P.alloc(cB.cout / 4, H2, W2);
-    d2.s16 = P.s16_mode;
     if (g.upscale_method == KP2D_UP_CONVTRANSPOSE) {
       // convB at the cell grid, then the transposed-conv upsampler as a pixel-shuffled 3x3 conv (heads.py:96-98)
       Act db = P.alloc(cB.cout, Hc, Wc);
-      db.s16 = P.s16_mode;
-      P.out_s16[0] = db.s16 ? 1 : 0;
       P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_NHWC, P.dry ? nullptr : P.ptr(db), db.C, 0, nullptr, 0, 0, 0, Hc, Wc);
-      P.out_s16[0] = d2.s16 ? 1 : 0;
       P.conv("desc_head.upsample", db, db.C, 0, nullptr, lk, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
       P.release(db);
     } else {
-      P.out_s16[0] = d2.s16 ? 1 : 0;
       P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
-    P.out_s16[0] = 0;
     P.release(d1);
     Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
     P.release(d2);
@@ -896,10 +852,10 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act g5{};
     int i;   // index of the second-to-last shuffle CBR
     if (g.use_attention) {
-      Act g0 = P.cbr(L + "0", xb, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // feeds LayerNorm
-      Act a1 = P.attention_module(L + "1", g0, /*pool=*/true, /*s16out=*/false);
+      Act g0 = P.cbr(L + "0", xb, nullptr, ST_NHWC);
+      Act a1 = P.attention_module(L + "1", g0, /*pool=*/true);
       P.release(g0);
-      Act a2 = P.attention_module(L + "2", a1, false, /*s16out=*/true);          // feeds convs.3
+      Act a2 = P.attention_module(L + "2", a1, false);
       P.release(a1);
       Act g4 = upconv(L + "3", hp + ".upsample", a2);
       P.release(a2);
@@ -955,7 +911,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     Act v1 = first("vlad_head.convlad1");
     Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
     P.release(v1);
-    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC, nullptr, /*s16out=*/false);   // NetVLAD reads fp32
+    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
     P.release(v2);
     const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
     if (only_enc || g.remove_netvlad) {
@@ -1078,15 +1034,8 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   if (cfg->n_classes < 1 || cfg->n_classes > 32) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "n_classes must be in [1,32]"); }
   int rc = describe(m);
   if (rc != KP2D_OK) { delete m; return rc; }
-  m->s16_ok = true;
-  for (int v : {m->c1, m->c2, m->c3, m->c4, m->c5, m->d1 / 4, cfg->encoder_dim}) m->s16_ok = m->s16_ok && (v % 16 == 0);
-  if (cfg->version == 3) m->s16_ok = m->s16_ok && ((m->c5 / 2) % 16 == 0);
-  const char* nd = getenv("KP2D_DMA");
-  m->use_dma = nd && nd[0] == '1';
   const char* nlanes = getenv("KP2D_LANES");
   if (nlanes) m->lanes = std::max(1, std::min(8, atoi(nlanes)));
-  const char* ns = getenv("KP2D_S16");
-  m->no_s16 = !(ns && ns[0] == '1') && !m->use_dma;
   *out = m;
   return KP2D_OK;
 }
@@ -1237,7 +1186,6 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     P.m = m; P.stream = lane == 0 ? caller : m->lane_streams[lane - 1];
     P.ws = (char*)workspace + (size_t)lane * per; P.dry = false;
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W;
-    P.s16_mode = m->precision == KP2D_PREC_F16X3 && m->s16_ok && !m->no_s16;
     P.arena.reset(per);
     FwdOut o{};
     o.x = x + (size_t)b0 * 3 * H * W;

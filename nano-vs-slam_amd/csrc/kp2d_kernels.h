@@ -34,14 +34,12 @@ struct ConvSrc { const float* p; int c, o; long bs, rs, ps; };   // channels tak
 struct ConvArgs {
   ConvSrc in0, in1;
   int taps;                           // 9 or 1
-  int in_s16;                         // sources are in the pre-split S16 format (f16x3 mode only)
   int prec;                           // 0: exact fp32 MFMA, 1: split-fp16 3xMFMA (weights packed as hi|lo halves)
   const float* w;                     // packed [group][cin_pad/KC][taps][ng][KC]
   const float* scale;                 // [npad]  BN: gamma/sqrt(var+eps); bias conv: 1
   const float* shift;                 // [npad]  BN: beta - mean*scale;   bias conv: bias
   float* out0; int os0, oo0;
   float* out1; int os1, oo1;
-  int out0_s16, out1_s16;             // 1: store in the pre-split S16 activation format (conv_common.h)
   int B, H, W;                        // conv resolution
   int cin, cout, npad;
   int act, store, nsplit;
@@ -55,12 +53,11 @@ struct Conv1aArgs {                   // backbone.conv1a: NCHW RGB in -> NHWC ou
   const float* w;                     // [27][cout]  (k = ci*9 + dy*3 + dx)
   const float* scale; const float* shift;
   float* out; int B, H, W, cout, act;
-  int out_s16;                        // 1: write the S16 pre-split format
 };
 
 int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s);
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
-int launch_conv3x3_s16(const ConvArgs& a, hipStream_t s);   // conv_s16.hip: S16 activations, LDS-DMA staging
+int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {
