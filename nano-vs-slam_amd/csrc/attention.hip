@@ -325,12 +325,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void att_split2(float x, float y, h16x2& hi, h16x2& lo) {
   const f32x2_ v = {x, y};
   hi = __builtin_convertvector(v, h16x2);
-  // x - float(hi) as a mixed-precision fma (v_fma_mix_f32 reads the fp16 half directly): one instruction per
-  // element instead of a conversion and a subtraction; the result is the same (the product is exact)
-  f32x2_ r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hi), "v"(x));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hi), "v"(y));
-  lo = __builtin_convertvector(r, h16x2);
+  // lo = fp16(x - float(hi)): v_fma_mixlo/mixhi_f16 read the fp16 half directly, form the (exact) fp32 difference and
+  // round it into one half of the destination — three instructions per two values (a v_fma_mix_f32 per value plus a
+  // packing conversion were four)
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(y));
+  lo = __builtin_bit_cast(h16x2, l);
 }
 __device__ __forceinline__ void att_split8(const float (&x)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
@@ -371,7 +372,11 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m = -INFINITY;
+  float m = 0.f;          // running reference of the online softmax: the maximum score so far (0 before the first tile)
+  f32x16 negm;            // -m in every register: the C operand of the score product
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  bool first = true;
   // Rows 16..31 of the V^T operand are padding (head dim <= 16).  Row 16 is set to ones, so that row 16 of O^T
   // accumulates the softmax denominator sum_k (ph + pl) on the matrix cores; the other padding rows are zeros.
   // Every lane reads its operand through a per-lane pointer (rows < 16: the staged V^T image, advancing per tile;
@@ -386,6 +391,8 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   for (int kc = 0; kc < T; kc += SKT) {
     __syncthreads();
     // stage: granule e = (key, 4 channels).  K row-major split rows; V transposed with the slot permutation.
+    // (Fetching the next chunk's granules into registers during the tiles of the current one measured slower:
+    // 3.89 vs 3.60 ms at 480x640 x 32 frames — the other workgroups of the CU already cover this round trip.)
     for (int e = tid; e < SKT * 4; e += NTHR) {
       const int key = e >> 2, q4 = e & 3;
       float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
@@ -416,10 +423,11 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
       // S^T tile: rows = keys 32*t32 + i
       const h16x8 kh = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 8 * h]);
       const h16x8 kl = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 16 + 8 * h]);
-      f32x16 sc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, sc, 0, 0, 0);
+      // The score accumulator starts at -m, the running reference of this query (kept as a 16-register vector that
+      // only changes when the reference moves): the products come out as s - m and the common tile — no key beats
+      // the reference — goes straight to exp2 with no per-score subtraction.  The kernel is bound by its VALU
+      // instruction count (11.6 per MFMA before this, profiles/r1_pmc_cfg4_summary.txt).
+      f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, negm, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sc, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sc, 0, 0, 0);
       const int kbase = kc + t32 * 32 + 4 * h;
@@ -428,19 +436,32 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
         for (int r = 0; r < 16; ++r)
           if (kbase + (r & 3) + 8 * (r >> 2) >= T) sc[r] = -INFINITY;
       }
-      float mx = m;
+      float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (__any(mx != m)) {                     // running maxima moved for some query of this wave: rescale
-        const float alpha = __builtin_amdgcn_exp2f(m - mx);       // first tile: exp2(-inf) = 0
-        m = mx;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) o[r] *= alpha;          // rows 0..15 (channels) and row 16 (denominator)
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);      // v_max3_f32
+      mx = fmaxf(mx, sc[15]);
+      {
+        // the other 16 keys of this query sit in lane ^ 32: v_permlane32_swap exchanges the wave halves on the VALU
+        // (ds_bpermute was an LDS round trip plus an lgkmcnt(0) in the middle of every tile)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
+      // first tile: the reference becomes the tile maximum whatever its sign (m and o start at 0); later it only rises
+      const float delta = first ? mx : fmaxf(mx, 0.f);
+      if (__any(delta != 0.f)) {                // some query of this wave moves its reference: shift and rescale
+        m += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] -= delta; negm[r] = -m; }
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int r = 0; r < 9; ++r) o[r] *= alpha;          // rows 0..15 (channels) and row 16 (denominator)
+        }
+      }
+      first = false;
       float p[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r]);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         h16x8 ph, pl;

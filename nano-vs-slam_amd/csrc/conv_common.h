@@ -51,15 +51,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// fp32 pair -> (hi, lo) fp16 pairs with hi = rn(x), lo = rn(x - hi): v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (reads the
-// fp16 half directly: x - float(hi) without a conversion), v_cvt_pk_f16_f32 (4 instructions per two values)
+// fp32 pair -> (hi, lo) fp16 pairs with hi = rn(x), lo = rn(x - hi): v_cvt_pk_f16_f32, then v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 (read the fp16 half directly, form the exact fp32 difference x - float(hi) and round it into one half
+// of the destination): three instructions per two values
 __device__ __forceinline__ void split2(float x, float y, f16x2& hi, f16x2& lo) {
   const f32x2 v = {x, y};
   hi = __builtin_convertvector(v, f16x2);
-  f32x2 r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hi), "v"(x));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hi), "v"(y));
-  lo = __builtin_convertvector(r, f16x2);
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(y));
+  lo = __builtin_bit_cast(f16x2, l);
 }
 
 }  // namespace kp2d
