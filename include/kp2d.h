@@ -162,6 +162,13 @@ int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** 
 #define KP2D_PREC_F16X3 1
 int kp2d_set_precision(kp2d_model* m, int mode);
 int kp2d_get_precision(const kp2d_model* m);
+/* Parity aid: the next kp2d_forward calls also copy ONE intermediate activation, as planar [B,C,H,W] fp32, to dst
+ * (device memory, capacity in floats; a forward that needs more fails with KP2D_ERR_ARG).  layer = a CBR's state-dict
+ * prefix ("backbone.conv1a", "backbone.conv3b", "vlad_head.convlad3", ...; a layer whose MaxPool2d is folded into its
+ * store yields the pooled tensor) or "<attention module>.att" / ".mff" (modules/segformer.py:217-220).  This is how
+ * the tests compare the kernels with the reference's recorded intermediates (tests/golden *_taps fixtures) layer by
+ * layer.  layer = NULL or dst = NULL switches it off. */
+int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_floats);
 /* frames per internal sub-batch (0 = automatic).  Intermediates of one sub-batch stay in the 256 MB Infinity Cache. */
 int kp2d_set_chunk_frames(kp2d_model* m, int frames);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "kp2d_set_chunk_frames": (C.c_int, [_P, C.c_int]),
     "kp2d_set_precision": (C.c_int, [_P, C.c_int]),
     "kp2d_get_precision": (C.c_int, [_P]),
+    "kp2d_set_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
     # include/kp2d_lightglue.h
     "kp2d_lg_create": (C.c_int, [C.POINTER(Kp2dLgConfig), C.POINTER(_P)]),
     "kp2d_lg_destroy": (None, [_P]),

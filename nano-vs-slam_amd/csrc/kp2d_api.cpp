@@ -145,6 +145,9 @@ struct kp2d_model {
   std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
   bool profiling = false;
+  std::string tap_name;   // kp2d_set_tap: one intermediate activation copied out (planar) during forward
+  float* tap_dst = nullptr;
+  size_t tap_cap = 0;
   bool small_grid_ng32 = !(getenv("KP2D_NG32") && getenv("KP2D_NG32")[0] == '0');   // KP2D_NG32=0: always 64-channel groups
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -557,7 +560,16 @@ struct Plan {
   Arena arena;
   bool dry = false;       // only size the arena
   int B, H, W;
+  int b0 = 0;             // first frame of this sub-batch in the caller's batch
   int rc = KP2D_OK;
+
+  // kp2d_set_tap: copy activation `a` (this sub-batch's frames) to the caller's planar [B,C,H,W] buffer
+  void tap(const std::string& name, const Act& a) {
+    if (dry || rc != KP2D_OK || !m->tap_dst || name != m->tap_name) return;
+    const size_t per = (size_t)a.C * a.H * a.W;
+    if (((size_t)b0 + B) * per > m->tap_cap) { rc = fail(KP2D_ERR_ARG, "tap '%s': buffer holds %zu floats, needs %zu", name.c_str(), m->tap_cap, ((size_t)b0 + B) * per); return; }
+    check(launch_nhwc_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H * a.W, a.PS ? a.PS : a.C, a.CO, stream), name.c_str());
+  }
 
   Act alloc(int C, int H_, int W_) {
     Act a;
@@ -697,6 +709,7 @@ struct Plan {
     release(kv);
     Act t = pw(p + ".att.fn.to_out", ao, ACT_NONE);
     release(ao);
+    tap(p + ".att", t);
     Act ln2 = layernorm(p + ".mff.norm", t);
     release(t);
     Act f0 = pw(p + ".mff.fn.net.0", ln2, ACT_NONE);
@@ -715,6 +728,7 @@ struct Plan {
     release(f1);
     Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC);
     release(f2);
+    tap(p + ".mff", f3);         // pooled when the module folds the following MaxPool2d
     return f3;
   }
   // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
@@ -738,6 +752,7 @@ struct Plan {
       out = alloc(c.cout / 4, Hc * 2, Wc * 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
+    tap(name, out);              // ST_NHWC_POOL: the pooled tensor (the full-resolution one is never written)
     return out;
   }
 };
@@ -766,6 +781,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
     P.prof_end();
   }
+  P.tap("backbone.conv1a", t1a);
   Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC);
   P.release(t1a);
   Act t2a = P.cbr("backbone.conv2a", p1, nullptr, ST_NHWC);
@@ -797,7 +813,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     if (merged) {
       int o = 0;
       for (const auto& pt : m->convs[m->conv_index.at("heads.first")].parts) {
-        if (pt.first == name) return Plan::view(mx, pt.second, o);
+        if (pt.first == name) { Act v = Plan::view(mx, pt.second, o); P.tap(name, v); return v; }
         o += pt.second;
       }
     }
@@ -830,6 +846,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
     P.release(d1);
+    P.tap("desc_head.convB", d2);     // the pixel-shuffled / transposed-conv upsampled tensor (heads.py:96-98)
     Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
     P.release(d2);
     P.conv("desc_head.confBb", d3, d3.C, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
@@ -1185,7 +1202,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     Plan P{};
     P.m = m; P.stream = lane == 0 ? caller : m->lane_streams[lane - 1];
     P.ws = (char*)workspace + (size_t)lane * per; P.dry = false;
-    P.B = std::min(chunk, B - b0); P.H = H; P.W = W;
+    P.B = std::min(chunk, B - b0); P.H = H; P.W = W; P.b0 = b0;
     P.arena.reset(per);
     FwdOut o{};
     o.x = x + (size_t)b0 * 3 * H * W;
@@ -1318,6 +1335,13 @@ int kp2d_set_precision(kp2d_model* m, int mode) {
 }
 
 int kp2d_get_precision(const kp2d_model* m) { return m ? m->precision : KP2D_ERR_ARG; }
+
+int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_floats) {
+  if (!m) return fail(KP2D_ERR_ARG, "null model");
+  if (!layer || !dst) { m->tap_name.clear(); m->tap_dst = nullptr; m->tap_cap = 0; return KP2D_OK; }
+  m->tap_name = layer; m->tap_dst = dst; m->tap_cap = capacity_floats;
+  return KP2D_OK;
+}
 
 int kp2d_set_chunk_frames(kp2d_model* m, int frames) {
   if (!m || frames < 0) return fail(KP2D_ERR_ARG, "bad argument");

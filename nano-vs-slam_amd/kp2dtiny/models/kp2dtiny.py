@@ -578,6 +578,18 @@ class _KP2DTinyBase(nn.Module):
         """Reference: kp2dtiny.py:490-491 -> NetVLAD.init_params (aggregators/netvlad.py:41-77, vladv2=False branch)."""
         self.vlad_head.netvlad.init_params(clsts, traindescs)
 
+    def forward_with_tap(self, x, layer: str, shape):
+        """forward(x) plus ONE intermediate activation as a planar [B, *shape] tensor (kp2d_set_tap, include/kp2d.h):
+        how the tests compare the kernels with the reference's recorded intermediates layer by layer."""
+        eng = self._get_engine(x.device)
+        tap = torch.full((x.shape[0],) + tuple(int(v) for v in shape), float("nan"), device=x.device)
+        _lib.check(eng.lib.kp2d_set_tap(eng.handle, layer.encode(), _ptr(tap), tap.numel()))
+        try:
+            out = self.forward(x)
+        finally:
+            _lib.check(eng.lib.kp2d_set_tap(eng.handle, None, None, 0))
+        return out, tap
+
     def only_encoder(self, x):
         """Reference: kp2dtiny.py:515-518 — backbone + VPR encoder, channel-wise L2-normalised (vpr.py:84-87)."""
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:

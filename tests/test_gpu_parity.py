@@ -19,10 +19,6 @@ TOL = 2e-4
 DEV = "cuda:0"
 
 
-def _built(meta):
-    return True
-
-
 def _run(model, x, H, W):
     with torch.no_grad():
         out = model(torch.from_numpy(x).to(DEV))
@@ -764,3 +760,69 @@ def test_precision_modes_agree_on_other_shapes(config, v3, B, H, W):
     for k in ("score", "coord", "feat", "seg", "vlad"):
         assert a[k].shape == b[k].shape
         assert float((a[k] - b[k]).abs().max()) < TOL, k
+
+
+def _maxpool2(a):
+    B, C, H, W = a.shape
+    return a.reshape(B, C, H // 2, 2, W // 2, 2).max(axis=(3, 5))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("name", ["v2_N_32x48_taps", "v3_SA_32x48_taps"])
+def test_intermediate_taps_on_device(name, precision):
+    """Every CBR / attention-module output the reference recorded (module hooks, make_golden.py), against the same
+    activation of the HIP path (kp2d_set_tap), layer by layer — the kernels themselves, not only the end of the net.
+    A layer whose MaxPool2d / PixelShuffle is folded into its store is compared with the pooled / shuffled reference."""
+    meta, z = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    model, _ = product_model(meta["config"], meta["v3"], meta["n_classes"])
+    model.set_precision(precision)
+    xt = torch.from_numpy(x).to("cuda:0")
+    ds = cfg["downsample"]
+    pool, same = _maxpool2, (lambda a: a)
+    layers = [("backbone.conv1a", "backbone.conv1a", same),
+              ("backbone.conv1b", "backbone.conv1b", pool if ds >= 2 else same),
+              ("backbone.conv2a", "backbone.conv2a", same),
+              ("backbone.conv2b", "backbone.conv2b", pool if ds >= 3 else same),
+              ("backbone.conv3a", "backbone.conv3a", same), ("backbone.conv3b", "backbone.conv3b", same),
+              ("backbone.conv4a", "backbone.conv4a", same), ("backbone.conv4b", "backbone.conv4b", same),
+              ("vlad_head.convlad1", "vlad_head.convlad1", same), ("vlad_head.convlad2", "vlad_head.convlad2", same),
+              ("vlad_head.convlad3", "vlad_head.convlad3", same), ("seg_head.convs.0", "seg_head.convs.0", same)]
+    if meta["v3"]:
+        layers += [("score_loc_head.convDa", "score_loc_head.convDa", same)]
+    else:
+        layers += [("score_head.convDa", "score_head.convDa", same), ("loc_head.convDa", "loc_head.convDa", same),
+                   ("desc_head.convA", "desc_head.convA", same), ("desc_head.convB", "desc_head.upsample", same),
+                   ("desc_head.confAa", "desc_head.confAa", same)]
+    if cfg["use_attention"]:
+        layers += [("seg_head.convs.1.att", "seg_head.convs.1.att", same), ("seg_head.convs.1.mff", "seg_head.convs.1.mff", pool),
+                   ("seg_head.convs.2.att", "seg_head.convs.2.att", same), ("seg_head.convs.2.mff", "seg_head.convs.2.mff", same),
+                   ("seg_head.convs.3", "seg_head.upsample", same), ("seg_head.convs.4", "seg_head.convs.4", same),
+                   ("seg_head.convs.5", "seg_head.upsample2", same), ("seg_head.convs.6", "seg_head.convs.6", same)]
+    else:
+        layers += [("seg_head.convs.1", "seg_head.convs.1", pool), ("seg_head.convs.2", "seg_head.convs.2", same),
+                   ("seg_head.convs.3", "seg_head.convs.3", same), ("seg_head.convs.4", "seg_head.upsample", same),
+                   ("seg_head.convs.5", "seg_head.convs.5", same), ("seg_head.convs.6", "seg_head.upsample2", same),
+                   ("seg_head.convs.7", "seg_head.convs.7", same)]
+    with torch.no_grad():
+        for layer, key, f in layers:
+            ref = f(z["tap:" + key])
+            _, tap = model.forward_with_tap(xt, layer, ref.shape[1:])
+            got = tap.cpu().numpy()
+            assert np.isfinite(got).all(), f"{layer}: the tap was not written"
+            assert np.max(np.abs(got - ref)) < TOL, (layer, float(np.max(np.abs(got - ref))))
+
+
+def test_dense_maps_complete_at_headline_size():
+    """KP2DTiny-S 240x320 (BASELINE config 2's frame): the FULL dense descriptor and segmentation maps against the
+    oracle (the reference fixtures hold a stride-4 subsample of them; the oracle is pinned on that subsample)."""
+    meta, z = load_golden("v2_S_240x320")
+    cfg, sd, x = golden_inputs(meta)
+    model, _ = product_model(meta["config"], meta["v3"], meta["n_classes"])
+    fwd, _, _ = _run(model, x, meta["H"], meta["W"])
+    ref = orc.forward(x, sd, cfg)
+    st = meta["dense_stride"]
+    for k in ("feat", "seg"):
+        assert np.max(np.abs(ref[k][:, :, ::st, ::st] - z["fwd_" + k])) < 1e-4      # the oracle on the reference's subsample
+        assert fwd[k].shape == ref[k].shape
+        assert np.max(np.abs(fwd[k] - ref[k])) < TOL, k                                # every pixel
