@@ -59,6 +59,8 @@ typedef struct kp2d_config {
   int32_t remove_netvlad;   /* to_export configs: "vlad" is the encoder map [B,enc,H/4,W/4] (vpr.py:84)          */
   int32_t depth;            /* depth=True: V2 second seg-like head, V3 third slice + featD (kp2dtiny.py:402-437)  */
   int32_t upscale_method;   /* KP2D_UP_PIXELSHUFFLE / KP2D_UP_CONVTRANSPOSE (to_mcu, kp2dtiny.py:271-273; base.py:80-117)  */
+  int32_t in_channels;      /* 3 = RGB frames; 1 = KP2DTinyV3(use_color=False) (kp2dtiny.py:718-721); 0 means 3.  A caller built
+                               against the struct without this field (struct_size 84) gets 3.                               */
 } kp2d_config;
 #define KP2D_UP_PIXELSHUFFLE 0
 #define KP2D_UP_CONVTRANSPOSE 1
@@ -98,7 +100,7 @@ int kp2d_import_packed(kp2d_model* m, const void* dev_src, void* stream);
 /* scratch the caller must provide for a (B,H,W) call; 256-byte aligned device memory */
 size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W);
 /* replaces: KP2DTinyV2.forward (kp2dtiny.py:552-591) / KP2DTinyV3.forward (:906-957).
- *   x      [B,3,H,W]  RGB in [-1,1]; H, W divisible by 8
+ *   x      [B,3,H,W]  RGB in [-1,1] ([B,1,H,W] for in_channels = 1); H, W divisible by 8
  *   score  [B,1,H/4,W/4]  sigmoid, un-bordered      shift [B,2,H/4,W/4]  tanh ("coord" key of forward)
  *   feat   [B,nfeatures,H/2,W/2] dense descriptors   seg   [B,n_classes,H/2,W/2] logits (V3 eval: probabilities)
  *   vlad   [B,kp2d_vlad_dim]: NetVLAD K*C; GeM / ConvAP encoder_dim*16; remove_netvlad: [B,encoder_dim,H/4,W/4] */

@@ -40,6 +40,7 @@ class Kp2dConfig(C.Structure):
         ("remove_netvlad", C.c_int32),
         ("depth", C.c_int32),
         ("upscale_method", C.c_int32),
+        ("in_channels", C.c_int32),
     ]
 
 

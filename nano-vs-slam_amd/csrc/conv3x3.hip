@@ -369,7 +369,7 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
 // K = 27 is too shallow for the matrix cores and the layer is HBM-bound (11 FLOP/B): one thread
 // per pixel, all output channels in registers, weights broadcast from LDS.
 // ---------------------------------------------------------------------------------------------
-template <int CO>
+template <int CO, int CIN>
 __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
   __shared__ __attribute__((aligned(16))) float4 s_o[256 * 4];
   static_assert(CO == 16, "conv1a: the output staging assumes 16 channels (4 float4 per pixel)");
@@ -386,15 +386,16 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
     // 27 taps as buffer loads: a tap outside the image gets an offset past the descriptor's range, which the
     // hardware answers with 0 — no lane-dependent branches (the ternary form compiled to 64 exec-mask branches).
     // The descriptor covers this block's frames only (offsets stay 32-bit for any batch size).
-    float v[27];
+    constexpr int NK = 9 * CIN;
+    float v[NK];
     {
       const size_t fb = ((size_t)blockIdx.x * 256) / ((size_t)W * H);          // first frame this block touches
       const size_t frames_left = (size_t)a.B - fb;
       const size_t nf = 256 / ((size_t)W * H) + 2;                              // frames a 256-pixel block can touch
-      const size_t span = (frames_left < nf ? frames_left : nf) * 3 * (size_t)H * W * sizeof(float);
+      const size_t span = (frames_left < nf ? frames_left : nf) * CIN * (size_t)H * W * sizeof(float);
       const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.x + fb * 3 * (size_t)H * W), 0, (int)span, 0x00020000);
-      const int fo = ((b - (int)fb) * 3 * H * W) * 4;
+          const_cast<float*>(a.x + fb * CIN * (size_t)H * W), 0, (int)span, 0x00020000);
+      const int fo = ((b - (int)fb) * CIN * H * W) * 4;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int yy = y + dy - 1;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
           const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
           const int o = ok ? fo + (yy * W + xx) * 4 : 0x7ffffff0;
 #pragma unroll
-          for (int ci = 0; ci < 3; ++ci)      // the plane stride goes into the scalar offset
+          for (int ci = 0; ci < CIN; ++ci)    // the plane stride goes into the scalar offset
             v[ci * 9 + dy * 3 + dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, ci * H * W * 4, 0));
         }
       }
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
     // of this kernel.
     const float* wg = a.w;
 #pragma unroll 3
-    for (int k = 0; k < 27; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const float vk = v[k];
 #pragma unroll
       for (int c = 0; c < CO; ++c) acc[c] = fmaf(vk, wg[k * CO + c], acc[c]);
@@ -447,11 +448,11 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
 // each thread writing its own 64-byte rows.  Not tuned: only the 16-wide layer is on a measured path.
 __global__ __launch_bounds__(256) void conv1a_wide_kernel(const Conv1aArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  const int CO = a.cout;
-  float* s_w = s_dyn;                 // [27][CO]
+  const int CO = a.cout, NK = 9 * a.cin;
+  float* s_w = s_dyn;                 // [NK][CO]
   float* s_sc = s_dyn + 27 * CO;      // [CO]
   float* s_sh = s_sc + CO;            // [CO]
-  for (int t = threadIdx.x; t < 27 * CO; t += 256) s_w[t] = a.w[t];
+  for (int t = threadIdx.x; t < NK * CO; t += 256) s_w[t] = a.w[t];
   for (int t = threadIdx.x; t < CO; t += 256) { s_sc[t] = a.scale[t]; s_sh[t] = a.shift[t]; }
   __syncthreads();
   const int H = a.H, W = a.W;
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(256) void conv1a_wide_kernel(const Conv1aArgs a) {
   float v[27];
 #pragma unroll
   for (int ci = 0; ci < 3; ++ci) {
-    const float* plane = a.x + ((size_t)b * 3 + ci) * H * W;
+    if (ci >= a.cin) { for (int t = 0; t < 9; ++t) v[ci * 9 + t] = 0.f; continue; }
+    const float* plane = a.x + ((size_t)b * a.cin + ci) * H * W;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y + dy - 1;
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(256) void conv1a_wide_kernel(const Conv1aArgs a) {
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
 #pragma unroll 3
     for (int k = 0; k < 27; ++k) {
+      if (k >= NK) break;
       const float4* wr = reinterpret_cast<const float4*>(&s_w[k * CO + c0]);
       const float vk = v[k];
 #pragma unroll
@@ -513,7 +516,9 @@ int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
   // conv1a_kernel addresses its taps with 32-bit byte offsets inside a descriptor of at most
   // 256 / (H W) + 2 frames
   if ((256 / ((size_t)a.H * a.W) + 2) * 3 * (size_t)a.H * a.W * sizeof(float) >= 0x7ffffff0u) return -1002;
-  if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16>), dim3(grid), dim3(256), 0, s, a);
+  if (a.cin != 3 && a.cin != 1) return -1001;
+  if (a.cout == 16 && a.cin == 3) hipLaunchKernelGGL((conv1a_kernel<16, 3>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cout == 16) hipLaunchKernelGGL((conv1a_kernel<16, 1>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cout % 16 == 0 && a.cout <= 256)
     hipLaunchKernelGGL(conv1a_wide_kernel, dim3(grid), dim3(256), (size_t)29 * a.cout * sizeof(float), s, a);
   else return -1001;

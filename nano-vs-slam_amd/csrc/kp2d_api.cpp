@@ -1,3 +1,4 @@
+#include <cstddef>
 // Host side of the C ABI declared in include/kp2d.h: model description, weight packing, the per-call
 // launch plan and the measurement hooks.  All arithmetic happens in the HIP kernels of this directory;
 // there is no CPU compute path here (a missing device or library is an error, never a fallback).
@@ -241,8 +242,8 @@ int describe(kp2d_model* m) {
   const kp2d_config& g = m->cfg;
   const int c1 = m->c1, c2 = m->c2, c3 = m->c3, c4 = m->c4, c5 = m->c5, d1 = m->d1;
   const bool v3 = g.version == 3;
-  // backbone (encoders.py:20-99).  conv1a is packed separately (Cin = 3).
-  add_spec(m, "backbone.conv1a.conv.weight", {c1, 3, 3, 3});
+  // backbone (encoders.py:20-99).  conv1a is packed separately (Cin = 3, or 1 for use_color=False).
+  add_spec(m, "backbone.conv1a.conv.weight", {c1, g.in_channels, 3, 3});
   add_spec(m, "backbone.conv1a.bn.weight", {c1});
   add_spec(m, "backbone.conv1a.bn.bias", {c1});
   add_spec(m, "backbone.conv1a.bn.running_mean", {c1});
@@ -349,7 +350,7 @@ int describe(kp2d_model* m) {
   // blob layout
   size_t off = 0;
   auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats, ALIGN / 4); return o; };
-  m->conv1a_w = take((size_t)27 * c1);
+  m->conv1a_w = take((size_t)9 * g.in_channels * c1);
   m->conv1a_sc = take(c1);
   m->conv1a_sh = take(c1);
   for (auto& c : m->convs) {
@@ -397,9 +398,10 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
   blob.assign(m->blob_floats, 0.f);
   const int c1 = m->c1;
   {
-    const auto& w = *host_get(m, "backbone.conv1a.conv.weight");   // [c1][3][3][3]
+    const auto& w = *host_get(m, "backbone.conv1a.conv.weight");   // [c1][cin][3][3]
+    const int nk = 9 * m->cfg.in_channels;
     for (int co = 0; co < c1; ++co)
-      for (int k = 0; k < 27; ++k) blob[m->conv1a_w + (size_t)k * c1 + co] = w[(size_t)co * 27 + k];
+      for (int k = 0; k < nk; ++k) blob[m->conv1a_w + (size_t)k * c1 + co] = w[(size_t)co * nk + k];
     bn_fold(m, "backbone.conv1a.bn", c1, &blob[m->conv1a_sc], &blob[m->conv1a_sh]);
   }
   for (const auto& c : m->convs) {
@@ -775,9 +777,9 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   if (!P.dry && P.rc == KP2D_OK) {
     Conv1aArgs a{};
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
-    a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk;
+    a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk; a.cin = g.in_channels;
     const double px = (double)B * H * W;
-    P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 27 * m->c1 * px, 4.0 * px * (3 + m->c1));
+    P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 9 * g.in_channels * m->c1 * px, 4.0 * px * (g.in_channels + m->c1));
     P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
     P.prof_end();
   }
@@ -1034,7 +1036,13 @@ int32_t kp2d_abi_version(void) { return KP2D_ABI_VERSION; }
 
 int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   if (!cfg || !out) return fail(KP2D_ERR_ARG, "null argument");
-  if (cfg->struct_size != (int32_t)sizeof(kp2d_config)) return fail(KP2D_ERR_ARG, "kp2d_config.struct_size mismatch");
+  // ABI evolution: the struct grew by in_channels; the shorter form (everything up to upscale_method) means RGB
+  constexpr int32_t kOldSize = (int32_t)offsetof(kp2d_config, in_channels);
+  if (cfg->struct_size != (int32_t)sizeof(kp2d_config) && cfg->struct_size != kOldSize)
+    return fail(KP2D_ERR_ARG, "kp2d_config.struct_size mismatch");
+  const int cin0 = (cfg->struct_size == kOldSize || cfg->in_channels == 0) ? 3 : cfg->in_channels;
+  if (cin0 != 3 && cin0 != 1) return fail(KP2D_ERR_UNSUPPORTED, "in_channels=%d (3 and 1 are built)", cin0);
+  if (cin0 == 1 && cfg->version != 3) return fail(KP2D_ERR_ARG, "in_channels=1 is KP2DTinyV3(use_color=False); V2 reads RGB");
   if (cfg->global_descriptor < KP2D_GD_NETVLAD || cfg->global_descriptor > KP2D_GD_CONVAP) return fail(KP2D_ERR_ARG, "bad global_descriptor");
   if (cfg->version != 2 && cfg->version != 3) return fail(KP2D_ERR_ARG, "version must be 2 or 3");
   int ndev = 0;
@@ -1042,7 +1050,9 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
     return fail(KP2D_ERR_HIP, "no HIP device visible: this library has no CPU path");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(KP2D_ERR_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
   auto* m = new kp2d_model();
-  m->cfg = *cfg;
+  std::memcpy(&m->cfg, cfg, (size_t)cfg->struct_size);
+  m->cfg.struct_size = (int32_t)sizeof(kp2d_config);
+  m->cfg.in_channels = cin0;
   m->c1 = cfg->channel_dims[0]; m->c2 = cfg->channel_dims[1]; m->c3 = cfg->channel_dims[2];
   m->c4 = cfg->channel_dims[3]; m->c5 = cfg->channel_dims[4]; m->d1 = cfg->channel_dims[5];
   if (m->c1 % 16 || m->c1 > 256) { delete m; return fail(KP2D_ERR_UNSUPPORTED, "channel_dims[0]=%d (conv1a kernels need a multiple of 16, <= 256)", cfg->channel_dims[0]); }
@@ -1205,7 +1215,7 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W; P.b0 = b0;
     P.arena.reset(per);
     FwdOut o{};
-    o.x = x + (size_t)b0 * 3 * H * W;
+    o.x = x + (size_t)b0 * g.in_channels * H * W;
     o.score = score ? score + (size_t)b0 * Hc * Wc : nullptr;
     o.shift = shift ? shift + (size_t)b0 * 2 * Hc * Wc : nullptr;
     o.feat = feat ? feat + (size_t)b0 * g.nfeatures * H2 * W2 : nullptr;

@@ -48,9 +48,10 @@ struct ConvArgs {
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip stores, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA
 };
 
-struct Conv1aArgs {                   // backbone.conv1a: NCHW RGB in -> NHWC out, Cin = 3
-  const float* x;                     // [B,3,H,W]
-  const float* w;                     // [27][cout]  (k = ci*9 + dy*3 + dx)
+struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC out, Cin = 3 (RGB) or 1 (use_color=False)
+  const float* x;                     // [B,cin,H,W]
+  const float* w;                     // [9*cin][cout]  (k = ci*9 + dy*3 + dx)
+  int cin;
   const float* scale; const float* shift;
   float* out; int B, H, W, cout, act;
 };

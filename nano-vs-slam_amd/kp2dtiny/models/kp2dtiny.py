@@ -379,6 +379,7 @@ class _KP2DTinyBase(nn.Module):
         cfg.remove_netvlad = int(bool(self.remove_netvlad))
         cfg.depth = int(bool(self.depth))
         cfg.upscale_method = _lib.UPSCALE_METHODS[self.upscale_method]
+        cfg.in_channels = 3 if getattr(self, "use_color", True) else 1     # KP2DTinyV3(use_color=False): kp2dtiny.py:718-721
         return cfg
 
     def _check_built(self):
@@ -475,8 +476,9 @@ class _KP2DTinyBase(nn.Module):
     # ---- reference API ------------------------------------------------------------------------
     def forward(self, x):
         """Reference: KP2DTinyV2.forward kp2dtiny.py:552-591 / KP2DTinyV3.forward :906-957."""
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError(f"expected [B,3,H,W] input, got {tuple(x.shape)}")
+        c0 = 3 if getattr(self, "use_color", True) else 1
+        if x.dim() != 4 or x.shape[1] != c0:
+            raise ValueError(f"expected [B,{c0},H,W] input, got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise TypeError("input must be float32")
         eng = self._get_engine(x.device)
@@ -592,8 +594,9 @@ class _KP2DTinyBase(nn.Module):
 
     def only_encoder(self, x):
         """Reference: kp2dtiny.py:515-518 — backbone + VPR encoder, channel-wise L2-normalised (vpr.py:84-87)."""
-        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
-            raise ValueError(f"expected float32 [B,3,H,W] input, got {x.dtype} {tuple(x.shape)}")
+        c0 = 3 if getattr(self, "use_color", True) else 1
+        if x.dim() != 4 or x.shape[1] != c0 or x.dtype != torch.float32:
+            raise ValueError(f"expected float32 [B,{c0},H,W] input, got {x.dtype} {tuple(x.shape)}")
         eng = self._get_engine(x.device)
         self._warn_if_training_semantics_expected()
         x = x.contiguous()
@@ -673,14 +676,12 @@ class KP2DTinyV3(_KP2DTinyBase):
                      use_attention=use_attention, mem_efficient=mem_efficient, upscale_method=upscale_method,
                      remove_netvlad=remove_netvlad, leaky_relu=leaky_relu, depth=depth, encoder_dim=encoder_dim,
                      global_descriptor_method=global_descriptor_method)
-        if not use_color:
-            raise NotImplementedError("use_color=False (1-channel input) is not built")
         self.with_drop, self.use_color, self.do_cross = with_drop, use_color, do_cross
         self.fuse_score_loc = True
         self.remove_softmax = remove_softmax
         c1, c2, c3, c4, c5, d1 = channel_dims
         mom = bn_momentum
-        self.backbone = _BackBone(3, c1, c2, c3, c4, 0.1)
+        self.backbone = _BackBone(3 if use_color else 1, c1, c2, c3, c4, 0.1)
         self.score_loc_head = _SimpleTaskHead(c4, c4, 3, mom)
         self.seg_head = _SegHead(c4, c5, c4 + c3, nClasses, d1, mom, use_attention, n_feat=nfeatures, depth=depth,
                                  upscale_method=upscale_method)

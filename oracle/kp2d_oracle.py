@@ -58,8 +58,9 @@ V3_CONFIGS = {
 
 
 def get_config(name: str, v3: bool = False) -> dict:
-    """``name`` may carry test-fixture suffixes: "+depth" (constructor depth=True) and "+mcu" (tiny_factory
-    to_mcu=True: upscale_method="convtranspose", leaky_relu=False — kp2dtiny.py:271-273)."""
+    """``name`` may carry test-fixture suffixes: "+depth" (constructor depth=True), "+mcu" (tiny_factory
+    to_mcu=True: upscale_method="convtranspose", leaky_relu=False — kp2dtiny.py:271-273) and "+gray"
+    (KP2DTinyV3(use_color=False): one input channel, kp2dtiny.py:718-721)."""
     mods = name.split("+")[1:]
     name = name.split("+")[0]
     table = V3_CONFIGS if v3 else V2_CONFIGS
@@ -76,6 +77,9 @@ def get_config(name: str, v3: bool = False) -> dict:
         cfg["depth"] = True
     if "mcu" in mods:
         cfg["upscale_method"], cfg["leaky_relu"] = "convtranspose", False
+    cfg["in_channels"] = 1 if "gray" in mods else 3
+    if "gray" in mods and not v3:
+        raise ValueError("use_color is a KP2DTinyV3 argument (kp2dtiny.py:682); KP2DTinyV2 always reads RGB")
     cfg["v3"] = v3
     return cfg
 
@@ -138,7 +142,7 @@ def state_dict_shapes(cfg: dict, n_classes: int) -> dict:
     nf, K, enc = cfg["nfeatures"], cfg["num_clusters"], cfg["encoder_dim"]
     v3, att = cfg["v3"], cfg["use_attention"]
     s = {}
-    for name, ci, co in [("conv1a", 3, c1), ("conv1b", c1, c2), ("conv2a", c2, c2), ("conv2b", c2, c3),
+    for name, ci, co in [("conv1a", cfg.get("in_channels", 3), c1), ("conv1b", c1, c2), ("conv2a", c2, c2), ("conv2b", c2, c3),
                          ("conv3a", c3, c3), ("conv3b", c3, c4), ("conv4a", c4, c4), ("conv4b", c4, c4)]:
         s.update(_cbr_shapes(f"backbone.{name}", ci, co))
     if v3:

@@ -92,6 +92,8 @@ CASES = {
     "v2_S_mcu_64x96": ("S+mcu", False, 28, 64, 96, 2, 8, False, 2, False),
     "v3_SA_mcu_64x96": ("S_A+mcu", True, 19, 64, 96, 1, 8, False, 2, False),
     "v2_NA_mcu_depth_64x96": ("N_A+mcu+depth", False, 28, 64, 96, 1, 8, False, 2, False),
+    # KP2DTinyV3(use_color=False): one-channel frames (kp2dtiny.py:682, :718-721); frames = channel 0 of the RGB ones
+    "v3_S_gray_64x96": ("S+gray", True, 19, 64, 96, 2, 8, False, 2, False),
 }
 
 
@@ -100,10 +102,13 @@ def build_reference(config, v3, n_classes):
     KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory = ref.KP2DTinyV2, ref.KP2DTinyV3, ref.get_config, ref.tiny_factory
     base, *mods = config.split("+")
     with contextlib.redirect_stdout(io.StringIO()):
-        if "depth" in mods:
+        if "depth" in mods or "gray" in mods:
             import copy
             conf = copy.deepcopy(get_config(base, to_mcu="mcu" in mods, v3=v3))
-            model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**conf, nClasses=n_classes, depth=True)
+            extra = {"depth": True} if "depth" in mods else {}
+            if "gray" in mods:
+                extra["use_color"] = False
+            model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**conf, nClasses=n_classes, **extra)
         else:
             model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -132,7 +137,7 @@ def run_case(name, out_dir):
     mine = orc.state_dict_shapes(cfg, ncls)
     assert list(mine.items()) == [(k, tuple(s)) for k, s in shapes.items()], f"{name}: state-dict layout drift"
 
-    x = synthetic_frames(B, H, W, seed, smooth)
+    x = synthetic_frames(B, H, W, seed, smooth)[:, :cfg["in_channels"]].copy()
     taps = {}
     hooks = []
     if want_taps:

@@ -33,6 +33,7 @@ def golden_inputs(meta):
     shapes = orc.state_dict_shapes(cfg, meta["n_classes"])
     sd = spread_state_dict(shapes, seed=meta["weight_seed"], head_gain=meta["head_gain"])
     x = synthetic_frames(meta["B"], meta["H"], meta["W"], meta["frame_seed"], meta["smooth"])
+    x = np.ascontiguousarray(x[:, :cfg["in_channels"]])       # "+gray": one-channel frames
     return cfg, sd, x
 
 
@@ -42,10 +43,13 @@ def product_model(config, v3, n_classes, device="cuda:0", seed=1234):
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from oracle.weights import spread_state_dict
     base, *mods = config.split("+")
-    if "depth" in mods:
+    if "depth" in mods or "gray" in mods:
         from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config
+        extra = {"depth": True} if "depth" in mods else {}
+        if "gray" in mods:
+            extra["use_color"] = False
         model = (KP2DTinyV3 if v3 else KP2DTinyV2)(**get_config(base, to_mcu="mcu" in mods, v3=v3),
-                                                   nClasses=n_classes, depth=True)
+                                                   nClasses=n_classes, **extra)
     else:
         model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}

@@ -37,8 +37,9 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_config_struct_layout_matches_header():
     from nano_vs_slam_amd import _lib
-    # struct_size, version, channel_dims[6], 8 scalars, device, global_descriptor, remove_netvlad, depth, upscale_method
-    assert ctypes.sizeof(_lib.Kp2dConfig) == 21 * 4
+    # struct_size, version, channel_dims[6], 8 scalars, device, global_descriptor, remove_netvlad, depth, upscale_method,
+    # in_channels
+    assert ctypes.sizeof(_lib.Kp2dConfig) == 22 * 4
     text = open(os.path.join(ROOT, "include", "kp2d.h")).read()
     body = text[text.index("typedef struct kp2d_config {"):text.index("} kp2d_config;")]
     names = re.findall(r"int32_t\s+([a-z_0-9]+)", body)

@@ -826,3 +826,35 @@ def test_dense_maps_complete_at_headline_size():
         assert np.max(np.abs(ref[k][:, :, ::st, ::st] - z["fwd_" + k])) < 1e-4      # the oracle on the reference's subsample
         assert fwd[k].shape == ref[k].shape
         assert np.max(np.abs(fwd[k] - ref[k])) < TOL, k                                # every pixel
+
+
+def test_config_struct_without_in_channels_still_creates_an_rgb_model():
+    """ABI evolution: a caller compiled against kp2d_config before in_channels existed (84 bytes) gets an RGB model."""
+    import ctypes as C
+    from nano_vs_slam_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.Kp2dConfig()
+    cfg.struct_size = 21 * 4
+    cfg.version = 2
+    for i, v in enumerate([16, 32, 32, 64, 64, 128]):
+        cfg.channel_dims[i] = v
+    cfg.nfeatures, cfg.n_classes, cfg.num_clusters, cfg.encoder_dim, cfg.downsample = 32, 28, 64, 64, 2
+    cfg.leaky_relu = 1
+    cfg.in_channels = 7          # garbage behind the end of the old struct must not be read
+    h = C.c_void_p()
+    _lib.check(lib.kp2d_create(C.byref(cfg), C.byref(h)))
+    key, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+    _lib.check(lib.kp2d_weight_info(h, 0, C.byref(key), shape, C.byref(nd)))
+    assert key.value == b"backbone.conv1a.conv.weight" and list(shape) == [16, 3, 3, 3]
+    lib.kp2d_destroy(h)
+    cfg.struct_size = 22 * 4
+    assert lib.kp2d_create(C.byref(cfg), C.byref(h)) != 0 and b"in_channels" in lib.kp2d_last_error()
+
+
+def test_use_color_false_rejects_rgb_frames():
+    model, _ = product_model("S+gray", True, 19)
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 64, 96, device=DEV))
+    with torch.no_grad():
+        out = model(torch.zeros(1, 1, 64, 96, device=DEV))
+    assert out["score"].shape == (1, 1, 16, 24)
