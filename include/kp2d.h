@@ -110,6 +110,15 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
                  float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* kp2d_forward with the frame front-end as the first layer's prologue: frames is uint8 [B,Hs,Ws,3]
+ * on the device; /255, the bilinear resize to (H, W) and .sub(0.5).mul(2) (src/evaluation/visual_odometry.py:77-87)
+ * happen while conv1a stages its input tile, so the float [B,3,H,W] frame is never written.  Bit-identical to
+ * kp2d_preprocess followed by kp2d_forward.  RGB models with a 16-channel first layer (every S / N / F config);
+ * others return KP2D_ERR_UNSUPPORTED (use the two calls). */
+int kp2d_forward_frames(kp2d_model* m, const uint8_t* frames, int B, int Hs, int Ws, int H, int W, uint32_t flags,
+                        float* score, float* shift, float* feat, float* seg, float* vlad, float* depth, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* replaces: post_processing (kp2dtiny.py:593-625 / :959-993).  `desc` and `seg_ids` may be NULL when the
  * module is in training mode (the reference skips sampling: kp2dtiny.py:615).
  *   score_out [B,1,Hc,Wc] border-zeroed   coord [B,2,Hc,Wc] pixels (ch0 = x)

@@ -79,6 +79,8 @@ SIGNATURES = {
     "kp2d_import_packed": (C.c_int, [_P, _P, _P]),
     "kp2d_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     "kp2d_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kp2d_forward_frames": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
+                                      C.c_size_t, _P]),
     "kp2d_post": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 11 + [_P, _P, _P, _P, C.c_int, _P]),
     "kp2d_vlad_dim": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "kp2d_select_topk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),

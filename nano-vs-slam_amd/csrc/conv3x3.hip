@@ -525,4 +525,90 @@ int launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv1a with the frame front-end as its prologue (src/evaluation/visual_odometry.py:77-87 +
+// encoders.py:20-29): reads the caller's uint8 HWC frames, and the /255 -> bilinear resize (align_corners=False, no
+// antialias) -> (v - 0.5) * 2 step happens while the 18 x 18 x 3 halo tile of a 16 x 16 output tile is staged into
+// LDS — the float [B,3,H,W] frame of kp2d_preprocess (12 B per pixel written, then read back) never exists.
+// Same arithmetic, in the same order, as preprocess_kernel (post.hip) followed by conv1a_kernel: bit-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1a_u8_kernel(const Conv1aArgs a, const unsigned char* __restrict__ frames, int Hs, int Ws) {
+  constexpr int CO = 16, HP = 18, HPP = 19;            // halo rows / LDS row pitch (floats)
+  __shared__ float s_in[3 * HP * HPP];
+  __shared__ __attribute__((aligned(16))) float4 s_o[256 * 4];
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const unsigned char* img = frames + (size_t)b * Hs * Ws * 3;
+  const bool same = Hs == H && Ws == W;
+  const float ry = (float)Hs / (float)H, rx = (float)Ws / (float)W;
+  for (int e = threadIdx.x; e < HP * HP; e += 256) {
+    const int py = e / HP, px = e - py * HP;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    float v[3] = {0.f, 0.f, 0.f};                       // the convolution's zero padding (of the NORMALISED frame)
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      if (same) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)img[((size_t)y * Ws + x) * 3 + c] / 255.0f;
+      } else {
+        const float sy = fmaxf(((float)y + 0.5f) * ry - 0.5f, 0.f);
+        const float sx = fmaxf(((float)x + 0.5f) * rx - 0.5f, 0.f);
+        const int ya = min((int)sy, Hs - 1), xa = min((int)sx, Ws - 1);
+        const int yb = min(ya + 1, Hs - 1), xb = min(xa + 1, Ws - 1);
+        const float wy = sy - (float)ya, wx = sx - (float)xa;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float a00 = (float)img[((size_t)ya * Ws + xa) * 3 + c] / 255.0f, a01 = (float)img[((size_t)ya * Ws + xb) * 3 + c] / 255.0f;
+          const float a10 = (float)img[((size_t)yb * Ws + xa) * 3 + c] / 255.0f, a11 = (float)img[((size_t)yb * Ws + xb) * 3 + c] / 255.0f;
+          v[c] = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (v[c] - 0.5f) * 2.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_in[(c * HP + py) * HPP + px] = v[c];
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const float* wg = a.w;
+#pragma unroll 3
+  for (int k = 0; k < 27; ++k) {
+    const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
+    const float vk = s_in[(ci * HP + ly + dy) * HPP + lx + dx];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = fmaf(vk, wg[k * CO + c], acc[c]);     // uniform index: scalar operands
+  }
+  const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float t = fmaf(acc[c], a.scale[c], a.shift[c]);
+    acc[c] = fmaxf(t, t * slope);
+  }
+#pragma unroll
+  for (int c = 0; c < CO; c += 4) s_o[threadIdx.x * 4 + c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  __syncthreads();
+  // a tile row (16 pixels x 64 B) is one contiguous KiB of the NHWC output: every wave store covers four of them
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = j * 256 + threadIdx.x;           // float4 index inside the tile: pixel e >> 2, quad e & 3
+    const int p = e >> 2, y = y0 + (p >> 4), x = x0 + (p & 15);
+    if (y < H && x < W) reinterpret_cast<float4*>(a.out + (((size_t)b * H + y) * W + x) * CO)[e & 3] = s_o[e];
+  }
+}
+
+int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, int Ws, hipStream_t s) {
+  if (a.cout != 16 || a.cin != 3) return -1001;     // the 16-wide RGB first layer (every S / N / F config)
+  const int grid = ((a.W + 15) >> 4) * ((a.H + 15) >> 4) * a.B;
+  hipLaunchKernelGGL(conv1a_u8_kernel, dim3(grid), dim3(256), 0, s, a, frames, Hs, Ws);
+  return (int)hipGetLastError();
+}
+
 }  // namespace kp2d

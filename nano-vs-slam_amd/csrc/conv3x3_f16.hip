@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   const bool uniform = ((c0 | a.cin) & (KC - 1)) == 0;
 
   auto prefetch_in = [&](int ch) {
+    if (KP2D_DBG_ON(4) || KP2D_DBG_ON(32)) {     // timing ablations (-DKP2D_ABLATE builds only; conv_common.h)
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it) rin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
     if (uniform) {
       // chunks never straddle the two sources and never run past cin (every S config)
       const bool first = ch * KC < c0;
@@ -175,22 +180,24 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   auto prefetch_w = [&](int ch) {
 #pragma unroll
     for (int it = 0; it < W_IT; ++it)
-      rw[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + THREADS * it) * 16, 0));
+      rw[it] = (KP2D_DBG_ON(4) || KP2D_DBG_ON(16)) ? make_float4(0.f, 0.f, 0.f, 0.f) : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + THREADS * it) * 16, 0));
   };
   prefetch_in(0);
   prefetch_w(0);
 
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();          // every wave is done reading the previous chunk's LDS images
-    commit_in();
+    if (!KP2D_DBG_ON(2)) commit_in();
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
+      if (KP2D_DBG_ON(2)) break;
       if (it == W_IT - 1 && W_G % THREADS != 0 && tid + THREADS * it >= W_G) continue;
       *reinterpret_cast<float4*>(sm + w_lds + it * (THREADS / 4) * 32) = rw[it];
     }
     __syncthreads();
     if (ch + 1 < nchunk) { prefetch_in(ch + 1); prefetch_w(ch + 1); }
 
+    if (!KP2D_DBG_ON(8))
 #pragma unroll
     for (int slot = 0; slot < 9; slot += 2) {
       const int t = slot_tap(slot);

@@ -760,6 +760,8 @@ struct Plan {
 };
 
 struct FwdOut {
+  const uint8_t* frames = nullptr;   // kp2d_forward_frames: uint8 [B,Hs,Ws,3]; x is null then
+  int Hs = 0, Ws = 0;
   const float* x;
   float *score, *shift, *feat, *seg, *vlad, *depth;
 };
@@ -779,8 +781,13 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
     a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk; a.cin = g.in_channels;
     const double px = (double)B * H * W;
-    P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 9 * g.in_channels * m->c1 * px, 4.0 * px * (g.in_channels + m->c1));
-    P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
+    if (o.frames) {
+      P.prof_begin("backbone.conv1a", "conv1a_u8", 2.0 * 27 * m->c1 * px, 3.0 * B * o.Hs * o.Ws + 4.0 * px * m->c1);
+      P.check(launch_conv1a_u8(a, o.frames, o.Hs, o.Ws, P.stream), "backbone.conv1a (uint8 frames)");
+    } else {
+      P.prof_begin("backbone.conv1a", "conv1a", 2.0 * 9 * g.in_channels * m->c1 * px, 4.0 * px * (g.in_channels + m->c1));
+      P.check(launch_conv1a(a, P.stream), "backbone.conv1a");
+    }
     P.prof_end();
   }
   P.tap("backbone.conv1a", t1a);
@@ -1170,11 +1177,14 @@ size_t kp2d_workspace_bytes(const kp2d_model* m, int B, int H, int W) {
   return std::max(per * nl, align_up(plan_bytes(mm, chunk1, H, W)));
 }
 
-int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
-                 float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
-                 void* stream) {
+static int forward_impl(kp2d_model* m, const float* x, const uint8_t* frames, int Hs, int Ws, int B, int H, int W,
+                        uint32_t flags, float* score, float* shift, float* feat, float* seg, float* vlad, float* depth,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;
-  if (!m || !x || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
+  if (!m || (!x && !frames) || !vlad || !workspace) return fail(KP2D_ERR_ARG, "null argument");
+  if (frames && (Hs < 1 || Ws < 1)) return fail(KP2D_ERR_ARG, "bad source frame size %dx%d", Hs, Ws);
+  if (frames && (m->cfg.in_channels != 3 || m->c1 != 16))
+    return fail(KP2D_ERR_UNSUPPORTED, "kp2d_forward_frames needs an RGB model with a 16-channel first layer (use kp2d_preprocess + kp2d_forward)");
   if (!only_enc && (!score || !shift || !feat || !seg)) return fail(KP2D_ERR_ARG, "null argument");
   if (!only_enc && m->cfg.depth && !depth) return fail(KP2D_ERR_ARG, "depth=1 model needs the depth output");
   if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised (kp2d_finalize_weights / kp2d_import_packed)");
@@ -1215,7 +1225,9 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W; P.b0 = b0;
     P.arena.reset(per);
     FwdOut o{};
-    o.x = x + (size_t)b0 * g.in_channels * H * W;
+    o.x = x ? x + (size_t)b0 * g.in_channels * H * W : nullptr;
+    o.frames = frames ? frames + (size_t)b0 * Hs * Ws * 3 : nullptr;
+    o.Hs = Hs; o.Ws = Ws;
     o.score = score ? score + (size_t)b0 * Hc * Wc : nullptr;
     o.shift = shift ? shift + (size_t)b0 * 2 * Hc * Wc : nullptr;
     o.feat = feat ? feat + (size_t)b0 * g.nfeatures * H2 * W2 : nullptr;
@@ -1236,6 +1248,20 @@ int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t fl
   }
   if (!first_err.empty()) g_err = first_err;
   return rc;
+}
+
+int kp2d_forward(kp2d_model* m, const float* x, int B, int H, int W, uint32_t flags, float* score, float* shift,
+                 float* feat, float* seg, float* vlad, float* depth, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  if (!x) return fail(KP2D_ERR_ARG, "null argument");
+  return forward_impl(m, x, nullptr, 0, 0, B, H, W, flags, score, shift, feat, seg, vlad, depth, workspace, workspace_bytes, stream);
+}
+
+int kp2d_forward_frames(kp2d_model* m, const uint8_t* frames, int B, int Hs, int Ws, int H, int W, uint32_t flags,
+                        float* score, float* shift, float* feat, float* seg, float* vlad, float* depth, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!frames) return fail(KP2D_ERR_ARG, "null argument");
+  return forward_impl(m, nullptr, frames, Hs, Ws, B, H, W, flags, score, shift, feat, seg, vlad, depth, workspace, workspace_bytes, stream);
 }
 
 int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float* feat, const float* seg, int B,

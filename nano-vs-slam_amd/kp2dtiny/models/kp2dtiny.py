@@ -481,14 +481,30 @@ class _KP2DTinyBase(nn.Module):
             raise ValueError(f"expected [B,{c0},H,W] input, got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise TypeError("input must be float32")
-        eng = self._get_engine(x.device)
-        self._warn_if_training_semantics_expected()
         x = x.contiguous()
         B, _, H, W = x.shape
+        return self._forward(x.device, B, H, W, x=x)
+
+    def forward_frames(self, frames, size=None):
+        """forward() straight from uint8 frames [B,Hs,Ws,3] on the device: /255, the bilinear resize to ``size`` = (H, W)
+        and .sub(0.5).mul(2) (src/evaluation/visual_odometry.py:77-87) run as the first layer's prologue
+        (kp2d_forward_frames): the float input tensor is never materialised.  Bit-identical to
+        forward(pipeline.frames_to_input(frames, device, size))."""
+        if frames.dim() != 4 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
+            raise ValueError("expected uint8 frames of shape [B,Hs,Ws,3]")
+        if frames.device.type != "cuda":
+            raise RuntimeError("the frame front-end runs on the HIP device only")
+        frames = frames.contiguous()
+        B, Hs, Ws, _ = frames.shape
+        H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
+        return self._forward(frames.device, B, H, W, frames=frames)
+
+    def _forward(self, dev, B, H, W, x=None, frames=None):
+        eng = self._get_engine(dev)
+        self._warn_if_training_semantics_expected()
         q = 2 * self.cell    # the segmentation head pools the cell grid once more
         if H % q or W % q:
             raise ValueError(f"H and W must be divisible by {q} (got {H}x{W}); reference README.md:143")
-        dev = x.device
         Hc, Wc = H // self.cell, W // self.cell
         H2, W2 = 2 * Hc, 2 * Wc        # dense maps sit one pixel-shuffle above the cell grid
         score = torch.empty(B, 1, Hc, Wc, device=dev)
@@ -502,8 +518,13 @@ class _KP2DTinyBase(nn.Module):
         ws = eng.workspace(B, H, W, dev)
         flags = 0 if self.training else _lib.KP2D_FWD_EVAL
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(eng.lib.kp2d_forward(eng.handle, _ptr(x), B, H, W, flags, _ptr(score), _ptr(shift), _ptr(feat),
-                                        _ptr(seg), _ptr(vlad), _ptr(depth), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        if frames is None:
+            _lib.check(eng.lib.kp2d_forward(eng.handle, _ptr(x), B, H, W, flags, _ptr(score), _ptr(shift), _ptr(feat),
+                                            _ptr(seg), _ptr(vlad), _ptr(depth), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        else:
+            _lib.check(eng.lib.kp2d_forward_frames(eng.handle, _ptr(frames), B, frames.shape[1], frames.shape[2], H, W, flags,
+                                                   _ptr(score), _ptr(shift), _ptr(feat), _ptr(seg), _ptr(vlad), _ptr(depth),
+                                                   _ptr(ws), ws.numel(), C.c_void_p(stream)))
         out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
         if self.depth:
             out["depth"] = depth        # already sigmoid (kp2dtiny.py:588-590 / :955-956)

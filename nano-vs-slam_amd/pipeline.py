@@ -21,9 +21,7 @@ from . import _lib
 from .selectors import select_keypoints, select_keypoints_host
 
 
-def frames_to_input(frames, device, size=None) -> torch.Tensor:
-    """uint8 [Hs,Ws,3] / [B,Hs,Ws,3] (numpy or torch) -> float32 [B,3,H,W] in [-1,1] on ``device``;
-    ``size`` = (H, W) resizes (visual_odometry.py:77-87: /255, kornia resize, .sub(0.5).mul(2))."""
+def _frames_on_device(frames, device) -> torch.Tensor:
     t = torch.as_tensor(np.asarray(frames) if not torch.is_tensor(frames) else frames)
     if t.dim() == 3:
         t = t.unsqueeze(0)
@@ -32,6 +30,19 @@ def frames_to_input(frames, device, size=None) -> torch.Tensor:
     t = t.to(device, non_blocking=True).contiguous()
     if t.device.type != "cuda":
         raise RuntimeError("the frame front-end runs on the HIP device only")
+    return t
+
+
+def _fused_front(net) -> bool:
+    """kp2d_forward_frames covers RGB models whose first layer has 16 channels (every S / N / F config)."""
+    return (os.environ.get("KP2D_FUSED_FRONT", "1") != "0" and getattr(net, "use_color", True)
+            and hasattr(net, "forward_frames") and int(net.channel_dims[0]) == 16)
+
+
+def frames_to_input(frames, device, size=None) -> torch.Tensor:
+    """uint8 [Hs,Ws,3] / [B,Hs,Ws,3] (numpy or torch) -> float32 [B,3,H,W] in [-1,1] on ``device``;
+    ``size`` = (H, W) resizes (visual_odometry.py:77-87: /255, kornia resize, .sub(0.5).mul(2))."""
+    t = _frames_on_device(frames, device)
     B, Hs, Ws, _ = t.shape
     H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
     x = torch.empty(B, 3, H, W, device=t.device)
@@ -46,9 +57,15 @@ def inference(net, image, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda
     """Returns (pts, feat, out) like the reference: for a single frame ``pts`` [n,2] and ``feat`` [n,C] numpy
     arrays; for a batch, lists of them.  ``out`` is the post-processed dict (device tensors)."""
     src_hw = tuple(image.shape[-3:-1])
-    x = frames_to_input(image, device, new_size)
-    _, _, H, W = x.shape
-    out = net(x)
+    if _fused_front(net):
+        # uint8 frames straight into the first layer (kp2d_forward_frames): no float frame in between
+        t = _frames_on_device(image, device)
+        H, W = (t.shape[1], t.shape[2]) if new_size is None else (int(new_size[0]), int(new_size[1]))
+        out = net.forward_frames(t, (H, W))
+    else:
+        x = frames_to_input(image, device, new_size)
+        _, _, H, W = x.shape
+        out = net(x)
     out = net.post_processing(out, H, W)
     scale = None
     if new_size is not None and (H, W) != src_hw:     # pts / scale: visual_odometry.py:81-83, 119-121
@@ -112,12 +129,19 @@ class FrameStream:
     def _step(self, slot):
         """The step on static buffers: everything here is enqueue-only (capturable)."""
         lib = _lib.load()
-        x = torch.empty(1, 3, self.H, self.W, device=self.dev)
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        Hs, Ws = self.dev_in[slot].shape[1:3]
-        _lib.check(lib.kp2d_preprocess(C.c_void_p(self.dev_in[slot].data_ptr()), 1, Hs, Ws, C.c_void_p(x.data_ptr()),
-                                       self.H, self.W, C.c_void_p(stream)))
-        out = self.net.post_processing(self.net(x), self.H, self.W)
+        if _fused_front(self.net) and not self.zero_copy:
+            # frame in device memory: the first layer reads it (kp2d_forward_frames)
+            fwd = self.net.forward_frames(self.dev_in[slot], (self.H, self.W))
+        else:
+            # zero-copy slot (pinned host memory): ONE pass over PCIe by the preprocess kernel; the fused first layer
+            # would fetch every halo / bilinear tap across the bus again
+            x = torch.empty(1, 3, self.H, self.W, device=self.dev)
+            stream = torch.cuda.current_stream(self.dev).cuda_stream
+            Hs, Ws = self.dev_in[slot].shape[1:3]
+            _lib.check(lib.kp2d_preprocess(C.c_void_p(self.dev_in[slot].data_ptr()), 1, Hs, Ws, C.c_void_p(x.data_ptr()),
+                                           self.H, self.W, C.c_void_p(stream)))
+            fwd = self.net(x)
+        out = self.net.post_processing(fwd, self.H, self.W)
         from .selectors import _cap, gather_keypoints, select_topk
         idx, _val, cnt = select_topk(out["score"], _cap(self.top_k, out["score"]), self.thr)
         pts, dsel = gather_keypoints(out["coord"], out["feat"], idx)

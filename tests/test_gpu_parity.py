@@ -858,3 +858,39 @@ def test_use_color_false_rejects_rgb_frames():
     with torch.no_grad():
         out = model(torch.zeros(1, 1, 64, 96, device=DEV))
     assert out["score"].shape == (1, 1, 16, 24)
+
+
+@pytest.mark.parametrize("config,v3,ncls", [("S", False, 28), ("N", True, 19)])
+def test_frames_fused_into_the_first_layer_are_bit_identical(config, v3, ncls):
+    """kp2d_forward_frames (uint8 frames -> /255 -> bilinear resize -> *2-1 as conv1a's prologue) against
+    kp2d_preprocess + kp2d_forward: the same arithmetic in the same order, so every output tensor is equal bit for bit —
+    without resize, down- and up-scaling, ragged tile edges (H, W not multiples of 16), several frames per call."""
+    from nano_vs_slam_amd.pipeline import frames_to_input
+    model, _ = product_model(config, v3, ncls)
+    rng = np.random.default_rng(5)
+    for B, Hs, Ws, size in [(2, 48, 64, None), (3, 150, 200, (72, 104)), (1, 60, 90, (120, 160)), (2, 376, 1241, (240, 320))]:
+        frames = torch.from_numpy(rng.integers(0, 256, (B, Hs, Ws, 3), dtype=np.uint8)).to(DEV)
+        with torch.no_grad():
+            ref = model(frames_to_input(frames, DEV, size))
+            got = model.forward_frames(frames, size)
+        assert set(got) == set(ref)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (k, Hs, Ws, size, float((got[k] - ref[k]).abs().max()))
+    with pytest.raises(ValueError):
+        model.forward_frames(torch.zeros(1, 48, 64, 3, device=DEV))            # not uint8
+    gray, _ = product_model("S+gray", True, 19)
+    from nano_vs_slam_amd._lib import Kp2dError
+    with pytest.raises(Kp2dError):
+        gray.forward_frames(torch.zeros(1, 64, 96, 3, dtype=torch.uint8, device=DEV))
+
+
+def test_inference_uses_the_fused_front_and_matches_the_two_step_path(monkeypatch):
+    from nano_vs_slam_amd import pipeline
+    model, _ = product_model("S", False, 28)
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, (2, 150, 200, 3), dtype=np.uint8)
+    pts_a, feat_a, _ = pipeline.inference(model, frames, (96, 128), nn_thresh=0.3, top_k=200)
+    monkeypatch.setenv("KP2D_FUSED_FRONT", "0")
+    pts_b, feat_b, _ = pipeline.inference(model, frames, (96, 128), nn_thresh=0.3, top_k=200)
+    for a, b in zip(pts_a + feat_a, pts_b + feat_b):
+        assert np.array_equal(a, b)
