@@ -353,11 +353,40 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   __shared__ __attribute__((aligned(16))) _Float16 Vc[16];                            // eight ones, eight zeros
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int hd = blockIdx.y, b = blockIdx.z;
+  // XCD affinity.  Workgroups are dealt round-robin over the 8 XCDs (L mod 8).  With a (tiles, heads, B) grid the
+  // query tiles of one (frame, head) spread over all eight L2s, each of which then fetches that pair's K / V — and,
+  // as a head only uses 64 B of every 128-B line of the q and kv rows, fetches each line twice as often again
+  // (PMC, 480x640 x 32 frames: 1.3 GB fetched per launch against 236 MB algorithmic).  A 1-D grid decoded as
+  // frame = xcd + 8 * (j / (tiles * heads))   (j = L / 8), heads in pairs inside a frame (below)
+  // keeps every workgroup of a frame on one XCD, so one L2 holds the frame's K / V and every q / kv line is used whole.  Needs B % 8 == 0 (the launcher falls back to (frame, head)
+  // pairs per XCD when only heads * B is a multiple of 8, and to the plain 3-D grid otherwise).
+  int hd, b, qblk;
+  if (gridDim.y == 1 && gridDim.z == 1 && a.heads * a.B > 1) {
+    const int tiles = (a.S + NTHR / 2 - 1) / (NTHR / 2);
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    if ((a.B & 7) == 0) {
+      const int per = tiles * a.heads;
+      b = xcd + 8 * (j / per);
+      const int r = j % per;
+      if ((a.heads & 1) == 0) {
+        // two heads at a time over all query tiles: their q / k / v segments are the two halves of the same 128-B
+        // lines, and only two heads' K / V (1.2 MB at 480x640) have to stay in the 4 MB L2 while the tiles stream by
+        const int hp = r / (2 * tiles), rr = r % (2 * tiles);
+        qblk = rr >> 1; hd = 2 * hp + (rr & 1);
+      } else {
+        hd = r % a.heads; qblk = r / a.heads;
+      }
+    } else {
+      const int pair = xcd + 8 * (j / tiles);
+      qblk = j % tiles; hd = pair % a.heads; b = pair / a.heads;
+    }
+  } else {
+    hd = blockIdx.y; b = blockIdx.z; qblk = blockIdx.x;
+  }
   const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
   const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
-  const int qi = blockIdx.x * (NTHR / 2) + wave * 32 + i;
+  const int qi = qblk * (NTHR / 2) + wave * 32 + i;
   // Q^T operand: lane (query i, h) holds channels 8h..8h+7, pre-multiplied by scale * log2(e) so that the
   // softmax runs on exp2 directly
   h16x8 qh, ql;
@@ -502,10 +531,15 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     // 256 queries per workgroup halve the K / V staging per query (18 % of the kernel at 128); short sequences
     // keep 128 so that the grid still covers the chip
     static const int big = getenv("KP2D_ATT_Q") ? atoi(getenv("KP2D_ATT_Q")) : 256;
-    if (big == 256 && (long)((a.S + 255) / 256) * a.heads * a.B >= 512)
-      hipLaunchKernelGGL((attention_split_kernel<512, 6>), dim3((a.S + 255) / 256, a.heads, a.B), dim3(512), 0, s, a);
-    else
-      hipLaunchKernelGGL((attention_split_kernel<256, 5>), dim3((a.S + 127) / 128, a.heads, a.B), dim3(256), 0, s, a);
+    // (tiles * pairs, 1, 1): XCD-affine pair order (see the kernel); needs pairs % 8 == 0
+    const bool affine = (a.heads * a.B) % 8 == 0 && !(getenv("KP2D_ATT_AFFINE") && getenv("KP2D_ATT_AFFINE")[0] == '0');
+    if (big == 256 && (long)((a.S + 255) / 256) * a.heads * a.B >= 512) {
+      const int tiles = (a.S + 255) / 256;
+      hipLaunchKernelGGL((attention_split_kernel<512, 6>), affine ? dim3(tiles * a.heads * a.B) : dim3(tiles, a.heads, a.B), dim3(512), 0, s, a);
+    } else {
+      const int tiles = (a.S + 127) / 128;
+      hipLaunchKernelGGL((attention_split_kernel<256, 5>), affine ? dim3(tiles * a.heads * a.B) : dim3(tiles, a.heads, a.B), dim3(256), 0, s, a);
+    }
     return (int)hipGetLastError();
   }
   const dim3 grid((a.S + 63) / 64, a.heads, a.B);
