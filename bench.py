@@ -271,10 +271,10 @@ def main():
         # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_collect.sh): bench.py
         # cannot run rocprofv3 around itself, so the per-launch figure measured on this workload is read back
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
             if B == 64 and (H, W) == (240, 320) and dom in tr["kernels"]:
                 roof["traffic"] = round(tr["kernels"][dom]["bytes_per_launch"])
-                roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)"
+                roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)"
                 roof["algorithmic_bytes_per_launch"] = round(a["bytes"] / a["launches"])
         except (OSError, KeyError, ValueError):
             pass
@@ -295,7 +295,7 @@ def main():
             "roofline": roof,
             "precision_modes": {k: {"value": round(frames / v, 1), "unit": "frames/s",
                                     "ms_per_step": round(v / args.steps * 1e3, 3),
-                                    "arithmetic": ("split-fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulate"
+                                    "arithmetic": ("split-fp16 operands on v_mfma_f32_16x16x32_f16, fp32 accumulate"
                                                    if k == "f16x3" else "exact fp32 on v_mfma_f32_32x32x2_f32")}
                                 for k, v in sorted(modes.items())},
         }

@@ -16,8 +16,8 @@ def family(name):
         args = n[n.index("<") + 1:n.index(">")].split(",")
         taps, prec = args[2].strip(), args[3].strip()
         return ("conv3x3" if taps == "9" else "conv1x1") + ("_f16x3" if prec == "1" else "_f32")
-    if n.startswith("conv3x3_s16_kernel"):
-        return "conv3x3_s16dma"
+    if n.startswith("conv3x3_f16x3_kernel"):      # conv3x3_f16.hip (16x16x32 MFMA), both tile widths
+        return "conv3x3_f16x3"
     return n.split("<")[0].replace("_kernel", "")
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerate everything under profiles/ that is quoted in DESIGN.md, in one GPU-box session:
-#   tools/refresh_profiles.sh [outdir]      (default gpurun_out/refresh; copy the results into profiles/ afterwards)
+#   tools/refresh_profiles.sh [outdir]      (default gpurun_out/refresh; copy the results into profiles/ as r<round>_* afterwards)
 # Steps are joined so that a failing GPU step stops the script (no GPU step runs after a timeout).
 set -eu -o pipefail
 OUT=${1:-gpurun_out/refresh}
