@@ -57,6 +57,7 @@ def test_stub_executes_and_matches_the_package():
     from oracle.weights import synthetic_frames
     stub = next(b for b in _python_blocks() if "lib.kp2d_forward(" in b)
     model, _ = product_model("S", False, 28)
+    model.set_precision("f16x3")       # the library's own default: the stub talks to the C ABI, which reads no KP2D_PRECISION
     x = torch.from_numpy(synthetic_frames(2, 64, 96, seed=5)).to("cuda:0")
     ns = {"model": model}
     cwd = os.getcwd()
