@@ -164,8 +164,13 @@ class LightGlue(nn.Module):
             assert key in data, f"Missing key {key} in data"
         if self.training:
             raise NotImplementedError("training mode (losses, checkpointing) is outside the built inference path")
-        if self.conf.depth_confidence > 0 or self.conf.width_confidence > 0:
-            raise NotImplementedError("early stopping / point pruning are not built (reference configs leave them at -1)")
+        if self.conf.depth_confidence > 0:
+            # the reference itself cannot run this: check_if_stop / get_pruning_mask read self.confidence_thresholds
+            # (lightglue.py:624, :636), which this fork never defines (only the method confidence_threshold, :615)
+            raise NotImplementedError("depth_confidence > 0 (early stopping) is not built; the reference raises "
+                                      "AttributeError on it (confidence_thresholds is never defined)")
+        if self.conf.width_confidence > 0:
+            raise NotImplementedError("width_confidence > 0 (point pruning) is not built (reference configs leave it at -1)")
         kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
         desc0, desc1 = data["descriptors0"].contiguous(), data["descriptors1"].contiguous()
         b, m, _ = kpts0.shape
