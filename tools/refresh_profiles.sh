@@ -13,9 +13,9 @@ timeout -k 10 300 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench.json"
 cat "$OUT/bench.json" | cut -c1-200
 
 step "rocprofv3 kernel stats, default two lanes"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o r -- python3 bench.py --no-cpu-baseline > "$OUT/stats2.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats2.log" 2>&1
 step "rocprofv3 kernel stats, single lane"
-KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o r -- python3 bench.py --no-cpu-baseline > "$OUT/stats1.log" 2>&1
+KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats1.log" 2>&1
 find "$OUT/stats1" "$OUT/stats2" -name "*kernel_trace.csv" -delete      # only the --stats summaries are kept
 
 step "per-layer table"
