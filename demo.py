@@ -25,7 +25,7 @@ def main():
     a = ap.parse_args()
     model = tiny_factory("S_A", 28, v3=True).cpu()
     if os.path.exists(a.weights):
-        model.load_state_dict(torch.load(a.weights, map_location=torch.device("cpu"))["state_dict"], strict=False)
+        model.load_state_dict(torch.load(a.weights, map_location=torch.device("cpu"), weights_only=True)["state_dict"], strict=False)
     else:
         from nano_vs_slam_amd.synthetic import spread_state_dict   # seeded stand-in weights (test infrastructure)
         sd = spread_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})

@@ -62,7 +62,13 @@ def load_checkpoint(filename, optimizer_key=None):
     filename = str(filename)
     assert filename.endswith(".ckpt"), "Error: filename is not a pth file"
     assert os.path.isfile(filename), "Error: checkpoint file not found"
-    checkpoint = torch.load(filename, map_location="cpu", weights_only=False)
+    # weights_only=True: the no-code loader (tensors, numbers, strings, dicts / lists of them — what train_multitask.py
+    # :553-562 saves: epoch, state_dict, optimizer state, config, results).  A checkpoint that needs arbitrary unpickling
+    # is refused with the loader's own message; there is no fallback to the unsafe mode.
+    try:
+        checkpoint = torch.load(filename, map_location="cpu", weights_only=True)
+    except Exception as e:  # pickle.UnpicklingError and friends
+        raise RuntimeError(f"{filename}: refused by the safe checkpoint loader (weights_only=True): {e}") from e
     optimizer = None
     if optimizer_key is not None:
         if optimizer_key in checkpoint.keys():

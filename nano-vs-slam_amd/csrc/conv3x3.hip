@@ -35,6 +35,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "device_guard.h"
 
 #ifndef KP2D_PITCH_NT1
 #define KP2D_PITCH_NT1 20
@@ -329,13 +330,8 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   // [pixel][N] staging tile of the fp32 NHWC epilogue; half the pixel rows per round for the weight-staged 64-channel tile
   const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float) / ((WST > 1 && NT == 2) ? 2 : 1);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC, WST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f32_kernel<KC, NT, TAPS, PREC, WST>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / (NT * 32);
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group

@@ -27,6 +27,7 @@
 // spilled at the 168-register budget of three workgroups per CU; this one fits 128 (two 512-thread workgroups per CU,
 // four waves per SIMD), keeps all nine weight slots resident and so has two barriers per chunk instead of six.
 #include "conv_common.h"
+#include "device_guard.h"
 
 namespace kp2d {
 
@@ -55,8 +56,11 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL: fp16 conversions that overflow clamp to +-65504
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   const int lane = tid & 63;
-  const int wave = (tid >> 6) & 3;                  // pixel rows 4 wave .. 4 wave + 3
   const int nh = tid >> 8;                          // 32-channel block of this wave
+  // pixel rows 4 wave .. 4 wave + 3.  The second channel block's waves take the row groups rotated by two, so that the
+  // two waves of a workgroup that share a SIMD (w and w + 4: waves go to the SIMDs cyclically) own different rows: in
+  // the ragged last tile row of a map (below) the waves that still have work are then spread over all four SIMDs.
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 2 * nh) & 3);
   // XCD-aware tile order (conv3x3.hip): every XCD gets a contiguous run of tiles
   int bid = blockIdx.x;
   {
@@ -70,6 +74,10 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   const int y0 = ty * TILE, x0 = tx * TILE;
   const int H = a.H, W = a.W;
   const int n0 = blockIdx.y * N;
+  // Ragged last tile row (map height not a multiple of 16: 120 -> 8 valid rows, 60 -> 12, 30 -> 14): a wave whose
+  // four rows lie wholly below the map multiplies and stores nothing (it still stages and joins every barrier).
+  // H = 120 / 60 otherwise spend 6.25 % of their matrix work on padding rows.
+  const bool busy = y0 + 4 * wave < H;
 
   f32x4 acc[4][NN];
 #pragma unroll
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
     __syncthreads();
     if (ch + 1 < nchunk) { prefetch_in(ch + 1); prefetch_w(ch + 1); }
 
-    if (!KP2D_DBG_ON(8))
+    if (!KP2D_DBG_ON(8) && busy)
 #pragma unroll
     for (int slot = 0; slot < 9; slot += 2) {
       const int t = slot_tap(slot);
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
 #define EPI_CH(n) (nh * 32 + (n) * 16 + lp)
 #define EPI_ROW(m, r) (wave * 4 + 2 * ((m) >> 1) + (((r) >> 1) & 1))
 #define EPI_COL(m, r) (8 * ((m) & 1) + 2 * lg + ((r) & 1))
+#define EPI_MVALID(m) busy
 #define EPI_THREADS THREADS
 #include "conv_epilogue.inc"
 #undef EPI_THREADS
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
 #undef EPI_CH
 #undef EPI_ROW
 #undef EPI_COL
+#undef EPI_MVALID
 }
 
 template <int NH>
@@ -266,13 +276,8 @@ static int launch_f(const ConvArgs& a, hipStream_t s) {
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   const size_t lds_tile = (size_t)16 * 16 * N * sizeof(float);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / N;
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group

@@ -68,6 +68,9 @@ struct ConvPack {
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
   size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows of w * 2^e, scale * 2^-e (pack())
   size_t w16n_off = 0;                        // the same rows in 32-channel groups (npad >= 64): small-grid launches
+  size_t wd_off = 0;                          // head layers (3x3, <= 4 output channels): fp32 [chunk][tap][4][16] for head3x3.hip
+  bool head() const { return kind == 0 && cout <= 4 && !shuffle && !tconv && parts.empty(); }
+  size_t wd_floats() const { return (size_t)((cin + 15) / 16) * 9 * 4 * 16; }
   size_t w_floats() const { return (size_t)((cin + kc - 1) / kc) * taps * npad * kc; }
   size_t w16_floats() const { return (size_t)((cin + 15) / 16) * taps * npad * 16; }
 };
@@ -149,6 +152,7 @@ struct kp2d_model {
   std::string tap_name;   // kp2d_set_tap: one intermediate activation copied out (planar) during forward
   float* tap_dst = nullptr;
   size_t tap_cap = 0;
+  bool head_dot = !(getenv("KP2D_HEAD_DOT") && getenv("KP2D_HEAD_DOT")[0] == '0');   // KP2D_HEAD_DOT=0: heads on the matrix-core kernels (A/B)
   bool small_grid_ng32 = !(getenv("KP2D_NG32") && getenv("KP2D_NG32")[0] == '0');   // KP2D_NG32=0: always 64-channel groups
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -364,6 +368,7 @@ int describe(kp2d_model* m) {
     c.w16_off = take(c.w16_floats());
     if (c.npad >= 64) c.w16n_off = take(c.w16_floats());
     c.sc16_off = take(c.npad);
+    if (c.head()) c.wd_off = take(c.wd_floats());
   }
   for (auto& kv : m->vecs) kv.second.off = take(kv.second.n);
   if (has_vlad) {
@@ -479,6 +484,11 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
       }
     }
     (void)ngroups;
+    if (c.head())   // dot-product form of the head layers: [chunk][tap][4][16], zero rows / columns as padding
+      for (int co = 0; co < c.cout; ++co)
+        for (int ci = 0; ci < c.cin; ++ci)
+          for (int tap = 0; tap < 9; ++tap)
+            blob[c.wd_off + ((((size_t)(ci / 16) * 9 + tap) * 4 + co) * 16) + ci % 16] = w[((size_t)co * c.cin + ci) * 9 + tap];
     // split-fp16 pack (conv3x3.hip PREC 1): K walked in chunks of 16; each row is 16 hi halves then 16 lo
     // halves of w * 2^e; the epilogue scale carries the 2^-e.  e = 11 keeps the lo half of ordinary weights a normal
     // fp16; a layer with large weights (|w| * 2^11 would pass the fp16 range: |w| >= 16) takes the largest e that keeps
@@ -644,6 +654,16 @@ struct Plan {
     a.act = act; a.store = store; a.nsplit = nsplit;
     if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
     const double px = (double)B * Hc * Wc;
+    if (c.head() && store == ST_NCHW && s1.c == 0 && act != ACT_SOFTMAX_C && m->head_dot) {
+      // score / loc / depth heads: 1-4 output channels as an HBM-bound dot-product kernel (exact fp32 in both modes)
+      a.prec = 0;
+      a.w = m->blob + c.wd_off;
+      a.scale = m->blob + c.sc_off;
+      prof_begin(name, "conv3x3_head", 2.0 * 9 * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * 9 * c.cin * c.cout);
+      check(launch_head3x3(a, stream), name.c_str());
+      prof_end();
+      return;
+    }
     const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
                             : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
@@ -1315,7 +1335,7 @@ int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* 
 
 int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int H, int W, void* stream) {
   if (!frames || !x || B < 1 || Hs < 1 || Ws < 1 || H < 1 || W < 1) return fail(KP2D_ERR_ARG, "bad preprocess arguments");
-  DeviceGuard guard(frames, (hipStream_t)stream);
+  DeviceGuard guard(x, (hipStream_t)stream);     // the OUTPUT is always device memory (frames may be pinned host memory)
   int e = launch_preprocess(frames, x, B, Hs, Ws, H, W, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "preprocess kernel: %d", e);
   return KP2D_OK;

@@ -59,6 +59,7 @@ struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC 
 int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s);
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, int Ws, hipStream_t s);   // frame front-end fused in
+int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------

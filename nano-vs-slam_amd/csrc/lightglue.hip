@@ -13,6 +13,7 @@
 //  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + row max/argmax (filter_matches :403-404)
 //  lg_filter_kernel     mutual check, threshold, match scores (:405-416)
 #include "kp2d_kernels.h"
+#include "device_guard.h"
 
 namespace kp2d {
 
@@ -196,13 +197,8 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
   if ((a.k0 & 3) || (a.k1 & 3) || (a.xs0 & 3) || (a.k1 && (a.xs1 & 3))) return -1801;     // 16-byte staging loads
   if (a.epi == LG_EPI_ROTARY && ((a.hd & 1) || (a.rot_cols & 1) || !a.cs)) return -1802;
   const size_t lds = (size_t)K * (LG_ROWS + a.nout) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lg_linear_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&lg_linear_kernel))) return e;
   hipLaunchKernelGGL(lg_linear_kernel, dim3((a.rows + LG_ROWS - 1) / LG_ROWS), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "kp2d_kernels.h"
+#include "device_guard.h"
 
 namespace kp2d {
 
@@ -446,13 +447,8 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
     if (a.K * a.C <= 4096) {
       hipLaunchKernelGGL(netvlad_partial_kernel<16>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds1, s, a);
     } else {   // TINY_F: 64 clusters x 128 channels, 83 KB of LDS
-      static bool attr_done = false;
-      if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&netvlad_partial_kernel<32>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-      }
+      static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
+      if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&netvlad_partial_kernel<32>))) return e;
       hipLaunchKernelGGL(netvlad_partial_kernel<32>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds1, s, a);
     }
   }

@@ -11,6 +11,7 @@
 // Every float op that feeds an index decision is written with explicit round-to-nearest
 // intrinsics so hipcc's default fp-contraction cannot fuse it differently from the reference.
 #include "kp2d_kernels.h"
+#include "device_guard.h"
 
 namespace kp2d {
 
@@ -379,13 +380,8 @@ int launch_topk(const TopkArgs& a, hipStream_t s) {
   if (keff <= TOPK_SMALL_MAX) {
     hipLaunchKernelGGL(topk_kernel<256>, dim3(a.B), dim3(256), lds, s, a, kpow);
   } else {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<1024>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_done = true;
-    }
+    static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
+    if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&topk_kernel<1024>))) return e;
     hipLaunchKernelGGL(topk_kernel<1024>, dim3(a.B), dim3(1024), lds, s, a, kpow);
   }
   return (int)hipGetLastError();

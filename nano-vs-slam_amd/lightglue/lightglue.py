@@ -109,7 +109,7 @@ class LightGlue(nn.Module):
         self._sig = None
         self._ws = None
         if weights_path is not None:
-            self.load_state_dict(torch.load(weights_path))
+            self.load_state_dict(torch.load(weights_path, map_location="cpu", weights_only=True))
 
     # ---- engine plumbing ----------------------------------------------------------------------
     def _engine(self, device):

@@ -33,7 +33,7 @@ class KP2DtinyFrontend(object):
         self.net = tiny_factory(config, nClasses, to_export=False, to_mcu=False, v3=v3)
         self.net.sample_segmentation = semantic_filter
         if self.weights_path is not None:
-            self.net.load_state_dict(torch.load(weights_path, map_location=torch.device("cpu"))["state_dict"])
+            self.net.load_state_dict(torch.load(weights_path, map_location=torch.device("cpu"), weights_only=True)["state_dict"])
         self.net.eval()
         self.net.training = False
         self.net = self.net.to(self.device)

@@ -42,6 +42,41 @@ def test_load_checkpoint_contract(tmp_path, capsys):
         load_checkpoint(str(tmp_path / "missing.ckpt"))
 
 
+class _Payload:
+    """A pickled callable: what a hostile .ckpt would carry.  The safe loader must refuse it, not run it."""
+    def __reduce__(self):
+        return (os.system, ("echo kp2d-ckpt-code-ran > /dev/null",))
+
+
+def test_checkpoint_with_pickled_code_is_refused(tmp_path):
+    sys.path.insert(0, ROOT)
+    from eval_multitask import load_checkpoint
+    bad = tmp_path / "hostile.ckpt"
+    torch.save({"state_dict": {"a": torch.zeros(1)}, "hook": _Payload()}, bad)
+    with pytest.raises(RuntimeError, match="safe checkpoint loader"):
+        load_checkpoint(str(bad))
+    # a training checkpoint as train_multitask.py:553-562 writes it (optimizer state with tensors, epoch, nested dicts)
+    good = tmp_path / "train.ckpt"
+    opt = {"state": {0: {"step": torch.tensor(3.0), "exp_avg": torch.ones(2, 3)}}, "param_groups": [{"lr": 1e-3, "params": [0]}]}
+    torch.save({"epoch": 12, "state_dict": {"a.weight": torch.ones(2, 3)}, "optimizer": opt, "config": {"name": "S", "v3": False},
+                "start_results": {"keypoints": [0.1, 0.2]}, "current_results": None}, good)
+    sd, o, info = load_checkpoint(str(good), optimizer_key="optimizer")
+    assert torch.equal(sd["a.weight"], torch.ones(2, 3)) and o["param_groups"][0]["lr"] == 1e-3 and info["epoch"] == 12
+
+
+def test_no_product_file_unpickles():
+    """Every torch.load of the product passes weights_only=True (reference utils/utils.py:13 uses the unsafe default)."""
+    import re
+    files = ["eval_multitask.py", "demo.py", "bench.py", "__graft_entry__.py"]
+    for base in ("nano-vs-slam_amd", "src", "lightglue", "tools"):
+        files += [os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, base, "**", "*.py"), recursive=True)]
+    for f in files:
+        text = open(os.path.join(ROOT, f)).read()
+        for m in re.finditer(r"torch\.load\(([^\n]*)", text):
+            assert "weights_only=True" in m.group(1), f"{f}: {m.group(0)}"
+        assert "pickle.load" not in text and "weights_only=False" not in text, f
+
+
 def test_cli_accepts_every_reference_flag():
     """Every ``--flag`` the reference's parser defines (eval_multitask.py:35-94) parses here too."""
     sys.path.insert(0, ROOT)
