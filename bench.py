@@ -11,8 +11,12 @@ owns ``--batch`` frames (frame-batch sharding); the only collect
 weight broadcast.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (3x3-conv implicit GEMM): algorithmic FLOPs / HIP-event time per launch,
-                against the fp32 matrix-core peak (the path is compute-bound in fp32)
+  roofline      the dominant kernel (3x3-conv implicit GEMM): algorithmic FLOPs / HIP-event time per launch.  Peak: in
+                the default f16x3 arithmetic one fp32-grade product costs three fp16 MFMAs (v_mfma_f32_16x16x32_f16),
+                so the algorithmic peak is the dense fp16 matrix peak / 3 = 838.9 TFLOP/s; with --precision fp32 it is
+                the fp32 matrix peak 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32)
+  collective    (N > 1) the backend and rank count torch.distributed reports, and the one collective of the job: the
+                start-up weight broadcast (bytes, ms)
   cpu_baseline  the same workload on the host cores (oracle/torch_port.py, plain torch CPU ops), bounded sample
 """
 from __future__ import annotations
@@ -149,14 +153,37 @@ def cpu_baseline(args, sd_np):
                       f"forward+post+select, best of B in (1,8) = B{best_b}; " + "; ".join(log) + f"; cpu: {model_name}"}
 
 
+def newest_traffic_file():
+    """profiles/r<round>_traffic.json of the highest round (None if there is none)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")):
+        m = re.match(r"r(\d+)_traffic\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def file_commit(rel):
+    """Short hash of the commit that last changed `rel` (the GPU box has no .git: 'unknown' there)."""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or "unknown"
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        # the line's n_gpus must be what was asked for AND what ran: refuse anything else
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
     dev_index = local_rank % torch.cuda.device_count()     # one rank per GPU; wraps only in single-GPU rehearsals
@@ -182,8 +209,16 @@ def main():
     model = model.to(dev).eval()
     model.training = False
     model.set_precision(args.precision)
+    collective = None
     if world > 1:
-        broadcast_model_weights(model, dev, src=0)   # the one RCCL collective of the job
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        nbytes = broadcast_model_weights(model, dev, src=0)   # the one RCCL collective of the job
+        torch.cuda.synchronize(dev)
+        collective = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                      "broadcast_bytes": int(nbytes), "broadcast_ms": round((time.perf_counter() - t0) * 1e3, 3),
+                      "steady_state_collectives": 0}
 
     from nano_vs_slam_amd.sharding import shard_range
     if args.global_batch > 0:
@@ -211,6 +246,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    rank_fps = {}
+
     def timed(precision):
         """W untimed + K timed steps in one arithmetic mode; seconds for the K steps, MAX over ranks."""
         model.set_precision(precision)
@@ -225,6 +262,10 @@ def main():
             dt_ = time.perf_counter() - t0
         t = torch.tensor([dt_], dtype=torch.float64, device=dev)
         if world > 1:
+            mine = torch.tensor([B * args.steps / dt_], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_fps[precision] = [float(v.item()) for v in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -247,14 +288,12 @@ def main():
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         total_ms = sum(v["ms"] for v in agg.values())
         split = "f16x3" in dom
-        # f16x3: one fp32-grade product = three fp16 MFMAs, so the algorithmic peak is the fp16 peak / 3.
-        # The split attention kernel (head dim 16) additionally runs its P.V product on 32x32 tiles of which 16 rows
-        # are channels and the rest padding: 9 MFMAs (3 for S, 6 for P.V) per 2*32*32*16*2 algorithmic FLOPs = 2/9.
-        mfma_per_flop = (2.0 / 9.0) if dom == "attention_f16x3" else (1.0 / 3.0)
+        # f16x3: one fp32-grade product = three fp16 MFMAs, so the algorithmic peak is the fp16 peak / 3 — for every
+        # split kernel, the attention kernel included (its padded P.V tiles are the kernel's own inefficiency, not a
+        # property of the peak).
+        mfma_per_flop = 1.0 / 3.0
         peak = PEAK_F16_MFMA_TFLOPS * mfma_per_flop if split else PEAK_F32_MFMA_TFLOPS
-        note = ("dense fp16 MFMA 2516.6 TFLOP/s x 2/9 (split attention, head dim 16: 9 fp16 MFMAs per 32x32 score tile)"
-                if dom == "attention_f16x3" else
-                "dense fp16 MFMA 2516.6 TFLOP/s / 3 MFMAs per fp32-grade product (xh*wh + xh*wl + xl*wh)"
+        note = ("dense fp16 MFMA 2516.6 TFLOP/s / 3 MFMAs per fp32-grade product (xh*wh + xh*wl + xl*wh)"
                 if split else "fp32 MFMA v_mfma_f32_32x32x2_f32")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
@@ -268,15 +307,19 @@ def main():
             # a bare fp16 MFMA loop sustains 1571 TFLOP/s on this chip (clock drops to ~1.5 GHz under matrix load:
             # tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log) -> 523.7 TFLOP/s of fp32-grade products
             roof["frac_of_sustained_mfma"] = round(achieved / (1571.0 * mfma_per_flop), 4)
-        # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_collect.sh): bench.py
-        # cannot run rocprofv3 around itself, so the per-launch figure measured on this workload is read back
+        # HBM-side traffic of the dominant kernel: NOT measured in this run (bench.py cannot run rocprofv3 around
+        # itself).  It is read back from the newest committed PMC pass on this workload (tools/pmc_collect.sh ->
+        # tools/pmc_traffic.py -> profiles/r<round>_traffic.json); the file and the commit that last touched it are named.
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            tfile = newest_traffic_file()
+            tr = json.load(open(tfile))
             if B == 64 and (H, W) == (240, 320) and dom in tr["kernels"]:
                 roof["traffic"] = round(tr["kernels"][dom]["bytes_per_launch"])
-                roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)"
+                rel = os.path.relpath(tfile, ROOT)
+                roof["traffic_unit"] = (f"bytes per launch; not measured in this run: PMC FETCH_SIZE x2 + WRITE_SIZE from {rel} "
+                                        f"(git {file_commit(rel)}), collected by tools/pmc_collect.sh on this workload")
                 roof["algorithmic_bytes_per_launch"] = round(a["bytes"] / a["launches"])
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, TypeError):
             pass
         lb = LAYER_BOUNDARY_MB.get((H, W))
         if lb and args.config == "S" and not args.v3:
@@ -299,6 +342,11 @@ def main():
                                                    if k == "f16x3" else "exact fp32 on v_mfma_f32_32x32x2_f32")}
                                 for k, v in sorted(modes.items())},
         }
+        if collective is not None:
+            line["collective"] = collective
+            fr = rank_fps.get(args.precision, [])
+            if fr:
+                line["per_rank_frames_per_s"] = {"min": round(min(fr), 1), "max": round(max(fr), 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, sd_np)
             line["speedup_vs_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)

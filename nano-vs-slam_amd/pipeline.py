@@ -88,7 +88,10 @@ class FrameStream:
     selection, gather and the copies of the selected rows to pinned host memory — is captured once per slot into a HIP
     graph over static buffers and replayed with one call; frames go through ``slots`` (default 2) pinned staging buffers
     that the preprocess kernel reads in place, so the host's staging of frame n+1 and the caller's work on frame n-1's
-    keypoints run while frame n computes.  Same results as ``inference()``, bit for bit (same kernels, same order).
+    keypoints run while frame n computes.  Every slot has its OWN compute stream and its OWN engine workspace: one
+    frame's ~60 small launches fill a tenth of the chip, so the graphs of consecutive frames run side by side on the
+    GPU (on one shared stream they ran back to back and the stream's rate was one frame's latency).
+    Same results as ``inference()``, bit for bit (same kernels, same order within a frame).
 
         fs = FrameStream(net, (Hs, Ws), new_size=(240, 320))
         for pts, feat, out in fs.map(frames): ...          # or fs.submit(frame) ... fs.result()
@@ -110,7 +113,12 @@ class FrameStream:
         self.top_k = int(top_k)
         self.slots = int(slots)
         self.copy_stream = torch.cuda.Stream(self.dev)
-        self.compute_stream = torch.cuda.Stream(self.dev)
+        # one compute stream per slot (KP2D_FS_SHARED_STREAM=1: the single shared stream of the first version, for A/B)
+        shared = os.environ.get("KP2D_FS_SHARED_STREAM", "0") == "1"
+        one = torch.cuda.Stream(self.dev)
+        self.compute_streams = [one if shared else (one if s == 0 else torch.cuda.Stream(self.dev)) for s in range(self.slots)]
+        self.compute_stream = self.compute_streams[0]
+        self._slot_ws = [None] * self.slots        # per-slot engine workspace (the engine caches ONE otherwise)
         self.pin_in = [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
         self._pin_np = [p.numpy() for p in self.pin_in]
         # the preprocess kernel reads the frame straight out of the pinned slot (device-visible host memory: 230 KB over
@@ -129,6 +137,13 @@ class FrameStream:
     def _step(self, slot):
         """The step on static buffers: everything here is enqueue-only (capturable)."""
         lib = _lib.load()
+        # the forward takes its workspace from the engine's cache: give it this slot's own buffer, so that two slots'
+        # graphs never share scratch memory
+        eng = self.net._get_engine(self.dev)
+        if self._slot_ws[slot] is None:
+            need = eng.lib.kp2d_workspace_bytes(eng.handle, 1, self.H, self.W)
+            self._slot_ws[slot] = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.dev)
+        eng._ws = self._slot_ws[slot]
         if _fused_front(self.net) and not self.zero_copy:
             # frame in device memory: the first layer reads it (kp2d_forward_frames)
             fwd = self.net.forward_frames(self.dev_in[slot], (self.H, self.W))
@@ -162,7 +177,7 @@ class FrameStream:
             host = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, k, 2).pin_memory(),
                     torch.empty(1, k, cdim).pin_memory())
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.compute_stream):
+            with torch.cuda.graph(g, stream=self.compute_streams[s]):
                 out, pts, dsel, cnt = self._step(s)
                 host[0].copy_(cnt, non_blocking=True)
                 host[1].copy_(pts, non_blocking=True)
@@ -196,11 +211,12 @@ class FrameStream:
             with torch.cuda.stream(self.copy_stream):
                 self.dev_in[s].copy_(self.pin_in[s], non_blocking=True)
                 self.ev_up[s].record(self.copy_stream)
-        with torch.cuda.stream(self.compute_stream):
+        cs = self.compute_streams[s]
+        with torch.cuda.stream(cs):
             if not self.zero_copy:
-                self.compute_stream.wait_event(self.ev_up[s])
+                cs.wait_event(self.ev_up[s])
             self.graphs[s].replay()
-            self.ev_done[s].record(self.compute_stream)
+            self.ev_done[s].record(cs)
         self._pending.append(s)
 
     def result(self):

@@ -35,9 +35,9 @@ def broadcast_blob(blob: torch.Tensor | None, nbytes: int, device, src: int = 0,
     return buf
 
 
-def broadcast_model_weights(model, device, src: int = 0, group=None) -> None:
+def broadcast_model_weights(model, device, src: int = 0, group=None) -> int:
     """Rank ``src`` packs its weights on the device; every other rank imports the broadcast blob, so only one
-    rank needs the checkpoint (demo.py / eval_multitask.py load it once)."""
+    rank needs the checkpoint (demo.py / eval_multitask.py load it once).  Returns the blob's size in bytes."""
     rank = dist.get_rank(group)
     size = torch.zeros(1, dtype=torch.int64, device=device)
     blob = None
@@ -48,6 +48,7 @@ def broadcast_model_weights(model, device, src: int = 0, group=None) -> None:
     buf = broadcast_blob(blob, int(size.item()), device, src, group)
     if rank != src:
         model.load_packed_weights(buf)
+    return int(buf.numel() * buf.element_size())
 
 
 def gather_vlad(vlad_local: torch.Tensor, n_frames: int, group=None) -> torch.Tensor:

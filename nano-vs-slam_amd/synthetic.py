@@ -18,7 +18,8 @@ import zlib
 
 import numpy as np
 
-__all__ = ["spread_tensor", "spread_state_dict", "synthetic_frames", "seeded_linear_state_dict"]
+__all__ = ["spread_tensor", "spread_state_dict", "synthetic_frames", "seeded_linear_state_dict",
+           "trained_like_tensor", "trained_like_state_dict"]
 
 
 def _rng(seed: int, key: str) -> np.random.Generator:
@@ -65,6 +66,48 @@ def spread_tensor(key: str, shape, seed: int = 1234, head_gain: float = 1.0) -> 
 def spread_state_dict(shapes: dict, seed: int = 1234, head_gain: float = 1.0) -> dict:
     """shapes: {key: shape}.  Returns {key: np.ndarray}."""
     return {k: spread_tensor(k, s, seed, head_gain) for k, s in shapes.items()}
+
+
+def _trained_var(prefix: str, n: int, seed: int) -> np.ndarray:
+    """BatchNorm running_var of layer `prefix`: log-uniform over 1e-4 ... 1e2 (six decades, as trained nets show)."""
+    return (10.0 ** _rng(seed, prefix + ".bn.running_var").uniform(-4.0, 2.0, n)).astype(np.float32)
+
+
+def trained_like_tensor(key: str, shape, seed: int = 1234) -> np.ndarray:
+    """One tensor of the "trained-like" recipe: statistics a checkpoint has and the spread recipe lacks.
+
+      bn.running_var   log-uniform 1e-4 ... 1e2 per channel
+      conv weights     heavy-tailed (Student t, 3 degrees of freedom) around N(0, 2/fan_in); in a conv + BN block row c
+                       is scaled by sqrt(running_var[c]), so the conv's output variance is what its BatchNorm divides by
+                       (as in a trained net) and activations stay O(1) while weights span ~1e-3 ... 1e2
+      bn.running_mean  N(0, 0.3^2) * sqrt(running_var);  bn.weight U(0.3, 1.8);  bn.bias N(0, 0.3^2)
+    Everything else as spread_tensor."""
+    shape = tuple(int(s) for s in shape)
+    leaf = key.rsplit(".", 1)[-1]
+    parent = key.rsplit(".", 2)[-2] if key.count(".") >= 1 else ""
+    g = _rng(seed, key)
+    if parent == "bn" and leaf in ("running_var", "running_mean", "weight", "bias"):
+        prefix = key[: -len(".bn." + leaf)]
+        var = _trained_var(prefix, shape[0], seed)
+        if leaf == "running_var":
+            return var
+        if leaf == "running_mean":
+            return (g.standard_normal(shape) * 0.3 * np.sqrt(var)).astype(np.float32)
+        if leaf == "weight":
+            return g.uniform(0.3, 1.8, shape).astype(np.float32)
+        return (g.standard_normal(shape) * 0.3).astype(np.float32)
+    if leaf == "weight" and len(shape) == 4 and not key.endswith("netvlad.conv.weight"):
+        fan_in = int(np.prod(shape[1:]))
+        w = g.standard_t(3.0, shape) / np.sqrt(3.0) * np.sqrt(2.0 / fan_in)
+        if parent == "conv":   # AnnotatedConvBnReLUModel: <prefix>.conv.weight + <prefix>.bn.*
+            var = _trained_var(key[: -len(".conv.weight")], shape[0], seed)
+            w = w * np.sqrt(var).reshape(-1, 1, 1, 1)
+        return w.astype(np.float32)
+    return spread_tensor(key, shape, seed)
+
+
+def trained_like_state_dict(shapes: dict, seed: int = 1234) -> dict:
+    return {k: trained_like_tensor(k, s, seed) for k, s in shapes.items()}
 
 
 def synthetic_frames(B: int, H: int, W: int, seed: int = 7, smooth: bool = False) -> np.ndarray:

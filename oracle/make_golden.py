@@ -46,6 +46,7 @@ import torch  # noqa: E402
 orc = _load_by_path("_golden_kp2d_oracle", os.path.join(REPO, "oracle", "kp2d_oracle.py"))
 _weights = _load_by_path("_golden_weights", os.path.join(REPO, "oracle", "weights.py"))
 spread_state_dict, synthetic_frames = _weights.spread_state_dict, _weights.synthetic_frames
+state_dict_for = _weights.state_dict_for
 
 
 def reference_module():
@@ -94,10 +95,14 @@ CASES = {
     "v2_NA_mcu_depth_64x96": ("N_A+mcu+depth", False, 28, 64, 96, 1, 8, False, 2, False),
     # KP2DTinyV3(use_color=False): one-channel frames (kp2dtiny.py:682, :718-721); frames = channel 0 of the RGB ones
     "v3_S_gray_64x96": ("S+gray", True, 19, 64, 96, 2, 8, False, 2, False),
+    # trained-like statistics (nano-vs-slam_amd/synthetic.py::trained_like_tensor): BatchNorm running_var over six decades,
+    # heavy-tailed conv weights scaled per output channel — what the f16x3 operand split has to survive on a checkpoint
+    "v2_S_trained_120x160": ("S", False, 28, 120, 160, 1, 8, False, 1, False, "trained"),
+    "v3_SA_trained_64x96": ("S_A", True, 19, 64, 96, 1, 8, False, 1, False, "trained"),
 }
 
 
-def build_reference(config, v3, n_classes):
+def build_reference(config, v3, n_classes, recipe="spread"):
     ref = reference_module()
     KP2DTinyV2, KP2DTinyV3, get_config, tiny_factory = ref.KP2DTinyV2, ref.KP2DTinyV3, ref.get_config, ref.tiny_factory
     base, *mods = config.split("+")
@@ -112,7 +117,7 @@ def build_reference(config, v3, n_classes):
         else:
             model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = spread_state_dict(shapes)
+    sd = state_dict_for(recipe, shapes)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model.eval()
     model.training = False
@@ -130,8 +135,9 @@ def gaps(score_flat, ks, thr=0.7):
 
 
 def run_case(name, out_dir):
-    config, v3, ncls, H, W, B, seed, smooth, stride, want_taps = CASES[name]
-    model, shapes, sd = build_reference(config, v3, ncls)
+    config, v3, ncls, H, W, B, seed, smooth, stride, want_taps = CASES[name][:10]
+    recipe = CASES[name][10] if len(CASES[name]) > 10 else "spread"
+    model, shapes, sd = build_reference(config, v3, ncls, recipe)
     cfg = orc.get_config(config, v3)
     # the oracle's own key/shape table must equal the reference's registration order
     mine = orc.state_dict_shapes(cfg, ncls)
@@ -159,7 +165,7 @@ def run_case(name, out_dir):
 
     arrays = {}
     meta = dict(name=name, config=config, v3=v3, n_classes=ncls, H=H, W=W, B=B, frame_seed=seed, smooth=smooth,
-                weight_seed=1234, head_gain=1.0, dense_stride=stride, torch=torch.__version__,
+                weight_seed=1234, head_gain=1.0, weights=recipe, dense_stride=stride, torch=torch.__version__,
                 n_params=int(sum(p.numel() for p in model.parameters())))
     arrays["fwd_score"] = fwd_np["score"]
     arrays["fwd_shift"] = fwd_np["coord"]

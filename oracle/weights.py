@@ -20,5 +20,15 @@ seeded_linear_state_dict = _mod.seeded_linear_state_dict
 spread_state_dict = _mod.spread_state_dict
 spread_tensor = _mod.spread_tensor
 synthetic_frames = _mod.synthetic_frames
+trained_like_tensor = _mod.trained_like_tensor
+trained_like_state_dict = _mod.trained_like_state_dict
 
-__all__ = ["spread_state_dict", "synthetic_frames", "spread_tensor", "seeded_linear_state_dict"]
+
+def state_dict_for(recipe, shapes, seed=1234, head_gain=1.0):
+    """Weights of a fixture's recipe: "spread" (default) or "trained" (fixture meta key "weights")."""
+    if recipe == "trained":
+        return trained_like_state_dict(shapes, seed=seed)
+    return spread_state_dict(shapes, seed=seed, head_gain=head_gain)
+
+__all__ = ["spread_state_dict", "synthetic_frames", "spread_tensor", "seeded_linear_state_dict", "trained_like_tensor",
+           "trained_like_state_dict", "state_dict_for"]

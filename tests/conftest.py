@@ -28,20 +28,20 @@ def golden_names():
 def golden_inputs(meta):
     """Regenerate the (weights, frames) a fixture was produced from — nothing but seeds is stored."""
     from oracle import kp2d_oracle as orc
-    from oracle.weights import spread_state_dict, synthetic_frames
+    from oracle.weights import state_dict_for, synthetic_frames
     cfg = orc.get_config(meta["config"], meta["v3"])      # understands the "+depth" / "+mcu" fixture suffixes
     shapes = orc.state_dict_shapes(cfg, meta["n_classes"])
-    sd = spread_state_dict(shapes, seed=meta["weight_seed"], head_gain=meta["head_gain"])
+    sd = state_dict_for(meta.get("weights", "spread"), shapes, seed=meta["weight_seed"], head_gain=meta["head_gain"])
     x = synthetic_frames(meta["B"], meta["H"], meta["W"], meta["frame_seed"], meta["smooth"])
     x = np.ascontiguousarray(x[:, :cfg["in_channels"]])       # "+gray": one-channel frames
     return cfg, sd, x
 
 
-def product_model(config, v3, n_classes, device="cuda:0", seed=1234):
-    """The product model (HIP engine) with the seeded spread weights, in inference mode."""
+def product_model(config, v3, n_classes, device="cuda:0", seed=1234, recipe="spread"):
+    """The product model (HIP engine) with the seeded spread (or "trained"-like) weights, in inference mode."""
     import torch
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
-    from oracle.weights import spread_state_dict
+    from oracle.weights import state_dict_for
     base, *mods = config.split("+")
     if "depth" in mods or "gray" in mods:
         from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import KP2DTinyV2, KP2DTinyV3, get_config
@@ -53,7 +53,7 @@ def product_model(config, v3, n_classes, device="cuda:0", seed=1234):
     else:
         model = tiny_factory(base, n_classes, to_mcu="mcu" in mods, v3=v3)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = spread_state_dict(shapes, seed=seed)
+    sd = state_dict_for(recipe, shapes, seed=seed)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(device).eval()
     model.training = False
@@ -65,7 +65,31 @@ def repo_root():
     return ROOT
 
 
-def assert_topk_equivalent(idx, ref_scores_flat, ref_idx, tol=2e-5):
+# Cells that used the decision-boundary exemption (a keypoint set differing from the reference's only in cells whose
+# reference score lies within 2e-5 of the threshold / the k-th score).  Every use is recorded and printed in the
+# terminal summary; more than MAX_BOUNDARY_EXEMPT cells in one comparison fails.
+BOUNDARY_EXEMPT = []
+MAX_BOUNDARY_EXEMPT = 4
+
+
+def note_boundary_exempt(label, n_cells, n_compared):
+    BOUNDARY_EXEMPT.append((str(label), int(n_cells), int(n_compared)))
+    assert n_cells <= MAX_BOUNDARY_EXEMPT, f"{label}: {n_cells} cells needed the 2e-5 boundary exemption (max {MAX_BOUNDARY_EXEMPT})"
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not BOUNDARY_EXEMPT:
+        return
+    used = [(l, n, c) for l, n, c in BOUNDARY_EXEMPT if n]
+    total_cells = sum(c for _, _, c in BOUNDARY_EXEMPT)
+    terminalreporter.write_line(
+        f"keypoint-set comparisons: {len(BOUNDARY_EXEMPT)} ({total_cells} selected cells compared), "
+        f"{len(used)} of them used the 2e-5 boundary exemption for {sum(n for _, n, _ in used)} cells in all")
+    for l, n, c in used:
+        terminalreporter.write_line(f"  boundary exemption: {l}: {n} of {c} cells")
+
+
+def assert_topk_equivalent(idx, ref_scores_flat, ref_idx, tol=2e-5, label="top-k"):
     """Two correct fp32 implementations differ by ~1e-6 in score, so an ORDERED top-k list may swap
     neighbours whose scores are closer than that.  Demand: (1) the same SET, except for cells whose
     reference score is within ``tol`` of the k-th score; (2) the order is non-increasing in the
@@ -81,5 +105,6 @@ def assert_topk_equivalent(idx, ref_scores_flat, ref_idx, tol=2e-5):
     kth = ref_scores_flat[ref_idx].min()
     diff = np.setxor1d(idx, ref_idx)
     assert np.all(np.abs(ref_scores_flat[diff] - kth) <= tol), "top-k sets differ beyond rounding"
+    note_boundary_exempt(label, len(diff), len(ref_idx))
     s = ref_scores_flat[idx]
     assert np.all(s[1:] - s[:-1] <= tol), "top-k order is not score-descending"

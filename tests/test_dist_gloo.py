@@ -98,3 +98,18 @@ def test_shard_range_covers_cfg3():
     for n, w in [(7, 2), (100, 8), (5, 8)]:
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_bench_refuses_world_size_mismatch():
+    """bench.py's n_gpus must be what was asked for AND what ran: WORLD_SIZE != --gpus exits non-zero before any GPU work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 8" in (r.stderr + r.stdout)

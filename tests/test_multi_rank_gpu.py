@@ -99,3 +99,31 @@ def test_bench_two_ranks_global_batch():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 12 and j["config"]["frame_shards"] == 2
     assert j["scaling"] == "weak" and j["value"] > 0 and set(j["precision_modes"]) == {"f16x3", "fp32"}
     assert abs(j["value"] - 12 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01
+    # what the driver's 8-GPU run needs to prove about itself: backend, ranks the collective saw, the one broadcast
+    c = j["collective"]
+    assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["steady_state_collectives"] == 0
+    assert 1_000_000 < c["broadcast_bytes"] < 64_000_000 and c["broadcast_ms"] > 0
+    pr = j["per_rank_frames_per_s"]
+    assert 0 < pr["min"] <= pr["max"] and pr["min"] * 2 >= j["value"] * 0.5
+
+
+def test_bench_cfg3_shape_two_rank_rehearsal():
+    """BASELINE cfg 3 is `--gpus 8 --global-batch 256` (32 frames per GPU at 240x320); rehearsed here with the same
+    per-rank share on two ranks of one GPU: `--gpus 2 --global-batch 64`."""
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--global-batch", "64", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--profile-steps", "1", "--no-precision-modes"]
+    outs = _spawn([(cmd, dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)])
+    for rc, o, e in outs:
+        assert rc == 0, e[-3000:]
+    j = json.loads([ln for ln in outs[0][1].splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and "batch 32/GPU" in j["config"]["workload"]
+    assert j["collective"]["ranks_seen"] == 2
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)

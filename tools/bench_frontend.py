@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--pinned", action="store_true")
     ap.add_argument("--eager", action="store_true", help="batch 1 only: call inference() per frame instead of FrameStream")
+    ap.add_argument("--slots", type=int, default=2, help="batch 1 only: FrameStream slots (frames in flight)")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import FrameStream, inference
@@ -33,7 +34,7 @@ def main():
     src = torch.from_numpy(frames).pin_memory() if a.pinned else frames
     if a.batch == 1 and not a.eager:
         # the VO loop: one frame per call, replayed HIP graph + overlapped upload (pipeline.FrameStream)
-        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0")
+        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0", slots=a.slots)
         seq = [frames[0]] * a.steps
         for _ in fs.map(seq[:5]):
             pass
@@ -44,7 +45,9 @@ def main():
         ms = (time.perf_counter() - t0) / n * 1e3
         print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. H2D of uint8 frames and D2H of keypoints",
                           "value": round(1e3 / ms, 1), "ms_per_step": round(ms, 3), "batch": 1,
-                          "mode": "FrameStream (HIP graph replay, 2 pinned slots, upload overlapped)"}))
+                          "mode": f"FrameStream (HIP graph replay, {a.slots} pinned slots, "
+                                  + ("ONE shared compute stream" if os.environ.get("KP2D_FS_SHARED_STREAM") == "1"
+                                     else "a compute stream and workspace per slot") + ")"}))
         return
     for _ in range(3):
         inference(net, src, None, 0.7, 1000, "cuda:0")

@@ -16,9 +16,23 @@ def family(name):
         args = n[n.index("<") + 1:n.index(">")].split(",")
         taps, prec = args[2].strip(), args[3].strip()
         return ("conv3x3" if taps == "9" else "conv1x1") + ("_f16x3" if prec == "1" else "_f32")
+    if n.startswith("head3x3_kernel"):
+        return "conv3x3_head"
     if n.startswith("conv3x3_f16x3_kernel"):      # conv3x3_f16.hip (16x16x32 MFMA), both tile widths
         return "conv3x3_f16x3"
     return n.split("<")[0].replace("_kernel", "")
+
+
+# Kernels whose global loads are 16 bytes per lane (buffer_load_dwordx4 / float4): the only access width the guide's
+# "FETCH_SIZE reports exactly half" calibration covers.  Everything else (conv1a's 4-byte tap loads, torch's elementwise
+# kernels, copies) keeps the raw counter: "other access widths are uncalibrated" (MI355X_MICROARCH.md, HBM).
+WIDE_LOAD_KERNELS = ("conv3x3_f16x3", "conv3x3_f32", "conv1x1", "conv3x3_head", "head3x3", "netvlad_partial", "netvlad_finish",
+                     "attention", "channel_layernorm", "dwconv3x3", "seg_argmax4", "post", "lg_")
+
+
+def fetch_factor(kernel_name):
+    n = kernel_name.replace("void ", "").replace("kp2d::", "")
+    return 2 if any(n.startswith(w) or family(n).startswith(w) for w in WIDE_LOAD_KERNELS) else 1
 
 
 def main():
@@ -33,12 +47,14 @@ def main():
     res = {}
     for k in tot:
         if "FETCH_SIZE" in tot[k] and "WRITE_SIZE" in tot[k]:
-            rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / cnt[k]["FETCH_SIZE"]
+            ff = fetch_factor(k)
+            rd = tot[k]["FETCH_SIZE"] * 1024 * ff / cnt[k]["FETCH_SIZE"]
             wr = tot[k]["WRITE_SIZE"] * 1024 / cnt[k]["WRITE_SIZE"]
             res[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
-                      "launches_profiled": cnt[k]["FETCH_SIZE"]}
+                      "fetch_size_factor": ff, "launches_profiled": cnt[k]["FETCH_SIZE"]}
     meta = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_collect.sh on tools/layer_profile.py "
-                      "(KP2DTiny-S 240x320, 64 frames); FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes",
+                      "(KP2DTiny-S 240x320, 64 frames); KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction) only for kernels "
+                      "with 16-byte-per-lane loads (fetch_size_factor 2), raw otherwise (uncalibrated access widths)",
             "kernels": res}
     json.dump(meta, open(out, "w"), indent=1)
     print(json.dumps(meta, indent=1))
