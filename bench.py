@@ -317,7 +317,7 @@ def main():
                 roof["traffic"] = round(tr["kernels"][dom]["bytes_per_launch"])
                 rel = os.path.relpath(tfile, ROOT)
                 roof["traffic_unit"] = (f"bytes per launch; not measured in this run: PMC FETCH_SIZE x2 + WRITE_SIZE from {rel} "
-                                        f"(git {file_commit(rel)}), collected by tools/pmc_collect.sh on this workload")
+                                        f"(git {tr.get('source_commit') or file_commit(rel)}), collected by tools/pmc_collect.sh on this workload")
                 roof["algorithmic_bytes_per_launch"] = round(a["bytes"] / a["launches"])
         except (OSError, KeyError, ValueError, TypeError):
             pass

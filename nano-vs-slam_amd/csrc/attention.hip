@@ -343,14 +343,25 @@ __device__ __forceinline__ void att_split8(const float (&x)[8], h16x8& hi, h16x8
 }
 
 constexpr int SKT = 128;   // keys per LDS chunk (four 32-key tiles)
-constexpr int SKP = 40;    // K row pitch in halves: 16 hi | 16 lo | 8 pad  (80 B)
-constexpr int SVP = 40;    // V^T row pitch in halves: 32 keys | 8 pad
+constexpr int SKP = 40;    // K row pitch in halves: 16 hi | 16 lo | 8 pad  (80 B: conflict-free ds_read_b128 of 32 rows)
+constexpr int SVP = 96;    // V row pitch in halves: [16 hi | 1, 0 x 15 | 16 lo | 0 x 16 | 32 unused] = 192 B: the four key
+                           // rows of a transposed block read (64 B each per 32-lane half) land on disjoint banks
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// V is staged ROW-major ([key][16 hi | 16 lo], as K) and reaches the matrix cores as the V^T operand through
+// ds_read_b64_tr_b16: per group of 16 lanes the instruction reads a block of 4 rows (keys) x 16 columns (channels),
+// lane 4q + p supplying the address of row q, columns 4p .. 4p+3, and hands lane c of the group column c of the four
+// rows — the transposition is free.  (The first version wrote V^T into LDS with eight 2-byte stores per staged granule:
+// 44.6 % of the kernel's LDS-active cycles were bank conflicts, profiles/r2_pmc_cfg4_summary.txt.)
+__device__ __forceinline__ h16x4 lds_tr4(const _Float16* p) {
+  const fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+  return __builtin_bit_cast(h16x4, r);
+}
 
 template <int NTHR, int WPS>   // threads per workgroup (32 queries per wave), waves per SIMD asked of the compiler
 __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
-  __shared__ __attribute__((aligned(16))) _Float16 Vt[(SKT / 32) * 16 * 2 * SVP];   // [tile][chan][hi|lo][SVP]
-  __shared__ __attribute__((aligned(16))) _Float16 Vc[16];                            // eight ones, eight zeros
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[SKT * SVP];                     // [key][16 hi | 1,0.. | 16 lo | 0.. | -]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   // XCD affinity.  Workgroups are dealt round-robin over the 8 XCDs (L mod 8).  With a (tiles, heads, B) grid the
@@ -408,12 +419,19 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   bool first = true;
   // Rows 16..31 of the V^T operand are padding (head dim <= 16).  Row 16 is set to ones, so that row 16 of O^T
   // accumulates the softmax denominator sum_k (ph + pl) on the matrix cores; the other padding rows are zeros.
-  // Every lane reads its operand through a per-lane pointer (rows < 16: the staged V^T image, advancing per tile;
-  // padding rows: the constant block, not advancing), so the tile loop has no lane-dependent branch.
-  if (tid < 16) Vc[tid] = (_Float16)(tid < 8 ? 1.f : 0.f);
-  const _Float16* vph = (i < 16) ? &Vt[(i * 2) * SVP + 8 * h] : (i == 16 ? &Vc[0] : &Vc[8]);
-  const _Float16* vpl = (i < 16) ? vph + SVP : &Vc[8];
-  const int vstep = (i < 16) ? 16 * 2 * SVP : 0, vtoff = (i < 16) ? 16 : 0;
+  // V^T operand of k-step t (keys 16 t .. 16 t + 15 of the tile), lane-half h, element j = key 16 t + 8 (j >> 2) + 4 h +
+  // (j & 3) (the order the score accumulator hands P^T over in): two transposed block reads, keys 16 t + 4 h .. + 3 and
+  // 16 t + 8 + 4 h .. + 3.  Lane groups 0 / 2 (lanes 0-15, 32-47) are channels 0-15; groups 1 / 3 are the padding rows
+  // and read the 16 constant columns that follow the real ones in every image row ([1, 0 x 15] behind the hi half, zeros
+  // behind the lo half, written once here; the staging never touches them): ONE address formula for all 64 lanes, every
+  // per-read offset an immediate, EXEC full as the transposed read requires.
+  for (int e = tid; e < SKT * 4; e += NTHR) {
+    const int row = e >> 2, part = e & 3;      // parts 0, 1: columns 16..31 (behind hi); 2, 3: columns 48..63 (behind lo)
+    h16x8 c = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (part == 0) c[0] = (_Float16)1.f;
+    *reinterpret_cast<h16x8*>(&Vs[row * SVP + 16 + 32 * (part >> 1) + 8 * (part & 1)]) = c;
+  }
+  const _Float16* const vph = &Vs[(4 * h + ((lane & 15) >> 2)) * SVP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
   const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
   const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
 
@@ -437,16 +455,12 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
       *reinterpret_cast<h16x4*>(&Ks[key * SKP + 16 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
       att_split2(vv.x, vv.y, h0, l0);
       att_split2(vv.z, vv.w, h1, l1);
-      const int tile = key >> 5, kk32 = key & 31, rem = kk32 & 15;
-      const int pos = (kk32 >> 4) * 16 + ((rem >> 2) & 1) * 8 + (((rem >> 3) << 2) | (rem & 3));
-      _Float16* vt = &Vt[((tile * 16 + 4 * q4) * 2) * SVP + pos];
-      vt[0] = h0[0]; vt[SVP] = l0[0];
-      vt[2 * SVP] = h0[1]; vt[3 * SVP] = l0[1];
-      vt[4 * SVP] = h1[0]; vt[5 * SVP] = l1[0];
-      vt[6 * SVP] = h1[1]; vt[7 * SVP] = l1[1];
+      *reinterpret_cast<h16x4*>(&Vs[key * SVP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<h16x4*>(&Vs[key * SVP + 32 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
     }
     __syncthreads();
     const int ntile = min(SKT, T - kc + 31) >> 5;
+    const _Float16* vcur = vph;
     for (int t32 = 0; t32 < (SKT >> 5); ++t32) {
       if (t32 >= ntile) break;
       // S^T tile: rows = keys 32*t32 + i
@@ -496,12 +510,15 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
         h16x8 ph, pl;
         const float (&pp)[8] = *reinterpret_cast<const float (*)[8]>(&p[8 * t]);
         att_split8(pp, ph, pl);
-        const h16x8 vh = *reinterpret_cast<const h16x8*>(vph + t32 * vstep + t * vtoff);
-        const h16x8 vl = *reinterpret_cast<const h16x8*>(vpl + t32 * vstep + t * vtoff);
+        const h16x4 vh0 = lds_tr4(vcur + (16 * t) * SVP), vl0 = lds_tr4(vcur + (16 * t) * SVP + 32);
+        const h16x4 vh1 = lds_tr4(vcur + (16 * t + 8) * SVP), vl1 = lds_tr4(vcur + (16 * t + 8) * SVP + 32);
+        const h16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+        const h16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
       }
+      vcur += 32 * SVP;       // next 32-key tile
     }
   }
   float l = o[8];                 // row 16 of O^T lives in register 8 of the h = 0 lanes (row 20, zero, for h = 1)
@@ -538,7 +555,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((attention_split_kernel<512, 6>), affine ? dim3(tiles * a.heads * a.B) : dim3(tiles, a.heads, a.B), dim3(512), 0, s, a);
     } else {
       const int tiles = (a.S + 127) / 128;
-      hipLaunchKernelGGL((attention_split_kernel<256, 5>), affine ? dim3(tiles * a.heads * a.B) : dim3(tiles, a.heads, a.B), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attention_split_kernel<256, 4>), affine ? dim3(tiles * a.heads * a.B) : dim3(tiles, a.heads, a.B), dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();
   }

@@ -21,12 +21,25 @@ from . import _lib
 from .selectors import select_keypoints, select_keypoints_host
 
 
-def _frames_on_device(frames, device) -> torch.Tensor:
+def _as_frames(frames) -> torch.Tensor:
     t = torch.as_tensor(np.asarray(frames) if not torch.is_tensor(frames) else frames)
     if t.dim() == 3:
         t = t.unsqueeze(0)
     if t.dtype != torch.uint8 or t.shape[-1] != 3:
         raise ValueError("expected uint8 frames of shape [H,W,3] or [B,H,W,3]")
+    return t
+
+
+def _pinned_zero_copy(t: torch.Tensor) -> bool:
+    """Pinned host frames are read in place by the preprocess kernel (device-visible host memory: one pass over PCIe,
+    at the kernel's own rate) instead of an asynchronous copy first: the hipMemcpyAsync of a 14.7 MB pinned batch runs on
+    an SDMA engine and measured SLOWER than torch's staged copy of pageable memory (tools/bench_frontend.py)."""
+    return (t.device.type == "cpu" and t.is_pinned() and t.is_contiguous()
+            and os.environ.get("KP2D_PINNED_ZERO_COPY", "1") != "0")
+
+
+def _frames_on_device(frames, device) -> torch.Tensor:
+    t = _as_frames(frames)
     t = t.to(device, non_blocking=True).contiguous()
     if t.device.type != "cuda":
         raise RuntimeError("the frame front-end runs on the HIP device only")
@@ -42,11 +55,19 @@ def _fused_front(net) -> bool:
 def frames_to_input(frames, device, size=None) -> torch.Tensor:
     """uint8 [Hs,Ws,3] / [B,Hs,Ws,3] (numpy or torch) -> float32 [B,3,H,W] in [-1,1] on ``device``;
     ``size`` = (H, W) resizes (visual_odometry.py:77-87: /255, kornia resize, .sub(0.5).mul(2))."""
-    t = _frames_on_device(frames, device)
+    t = _as_frames(frames)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("the frame front-end runs on the HIP device only")
+    if not _pinned_zero_copy(t):
+        t = _frames_on_device(t, dev)
+        dev = t.device
+    elif dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     B, Hs, Ws, _ = t.shape
     H, W = (Hs, Ws) if size is None else (int(size[0]), int(size[1]))
-    x = torch.empty(B, 3, H, W, device=t.device)
-    stream = torch.cuda.current_stream(t.device).cuda_stream
+    x = torch.empty(B, 3, H, W, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.load().kp2d_preprocess(C.c_void_p(t.data_ptr()), B, Hs, Ws, C.c_void_p(x.data_ptr()), H, W,
                                            C.c_void_p(stream)))
     return x
@@ -57,7 +78,7 @@ def inference(net, image, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda
     """Returns (pts, feat, out) like the reference: for a single frame ``pts`` [n,2] and ``feat`` [n,C] numpy
     arrays; for a batch, lists of them.  ``out`` is the post-processed dict (device tensors)."""
     src_hw = tuple(image.shape[-3:-1])
-    if _fused_front(net):
+    if _fused_front(net) and not (torch.is_tensor(image) and _pinned_zero_copy(image)):
         # uint8 frames straight into the first layer (kp2d_forward_frames): no float frame in between
         t = _frames_on_device(image, device)
         H, W = (t.shape[1], t.shape[2]) if new_size is None else (int(new_size[0]), int(new_size[1]))
@@ -86,7 +107,7 @@ class FrameStream:
     One frame's step is ~60 dependent launches of a few microseconds each: enqueued one by one the host is the
     bottleneck (0.59 ms per frame).  Here the whole step — kp2d_preprocess, forward, post_processing, threshold/top-k
     selection, gather and the copies of the selected rows to pinned host memory — is captured once per slot into a HIP
-    graph over static buffers and replayed with one call; frames go through ``slots`` (default 2) pinned staging buffers
+    graph over static buffers and replayed with one call; frames go through ``slots`` (default 3: 2.5k, 4.2k, 6.0k, 4.7k frames/s with 1, 2, 3, 4 slots) pinned staging buffers
     that the preprocess kernel reads in place, so the host's staging of frame n+1 and the caller's work on frame n-1's
     keypoints run while frame n computes.  Every slot has its OWN compute stream and its OWN engine workspace: one
     frame's ~60 small launches fill a tenth of the chip, so the graphs of consecutive frames run side by side on the
@@ -99,7 +120,7 @@ class FrameStream:
     ``out`` holds the slot's static device tensors: valid until ``slots`` further frames have been submitted.
     """
 
-    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=2):
+    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=3):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("the frame front-end runs on the HIP device only")

@@ -396,10 +396,13 @@ def test_frame_stream_equals_inference_frame_by_frame(src_hw, new_size, top_k):
     assert len(want[0][0]) > 0
     with pytest.raises(RuntimeError):
         fs.result()                                                   # nothing in flight
-    fs.submit(frames[0]); fs.submit(frames[1])
+    for k in range(fs.slots):
+        fs.submit(frames[k])
     with pytest.raises(RuntimeError):
-        fs.submit(frames[2])                                          # both slots busy
-    fs.result(); fs.result()
+        fs.submit(frames[fs.slots])                                   # every slot busy
+    for k in range(fs.slots):
+        p, f, _ = fs.result()                                         # in order, although the slots' graphs overlap on the GPU
+        assert np.array_equal(p, want[k][0]) and np.array_equal(f, want[k][1])
     # new weights: same graphs, new numbers
     with torch.no_grad():
         model.loc_head.convDb.bias.add_(0.2)   # moves every keypoint
