@@ -53,16 +53,6 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   constexpr int KC = 16, Q = 4;
 
   const int tid = threadIdx.x;
-  if (a.skew > 0 && (int)blockIdx.x < 256 * (NH == 1 ? 3 : 2)) {
-    // EXPERIMENT (KP2D_SKEW): every launch starts all resident workgroups at once, so the whole chip loads, multiplies
-    // and stores in lockstep.  The workgroups of the first round that are not the first on their CU (LDS allocation not
-    // at offset 0) start `skew` cycles late; equal tile times keep that offset for the rest of the launch.
-    const unsigned lds_alloc = __builtin_amdgcn_s_getreg((21 - 1) << 11 | 0 << 6 | 6);   // HW_REG_LDS_ALLOC (id 6), all 32 bits
-    if ((lds_alloc & 0xfff) != 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.skew) __builtin_amdgcn_s_sleep(8);
-    }
-  }
   // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL: fp16 conversions that overflow clamp to +-65504
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   const int lane = tid & 63;

@@ -637,7 +637,6 @@ struct Plan {
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
     const bool split = m->precision == KP2D_PREC_F16X3;
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
-    { static const int skew = getenv("KP2D_SKEW") ? atoi(getenv("KP2D_SKEW")) : 0; a.skew = skew; }
     a.prec = split ? 1 : 0;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;

@@ -46,7 +46,6 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip stores, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA
-  int skew;                           // experiment (KP2D_SKEW, shader cycles): first-round workgroups that are not the first on their CU start late
 };
 
 struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC out, Cin = 3 (RGB) or 1 (use_color=False)
