@@ -28,39 +28,56 @@
 // four waves per SIMD), keeps all nine weight slots resident and so has two barriers per chunk instead of six.
 #include "conv_common.h"
 #include "device_guard.h"
+#include <cstdlib>
 
 namespace kp2d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int F_ROWS = 18, F_PITCH = 20, F_PXB = 32;
-constexpr int F_LO = F_ROWS * F_PITCH * F_PXB;      // byte offset of the lo plane (11520)
-constexpr int F_W = 2 * F_LO;                       // weight planes start behind the two input planes
+constexpr int F_ROWS = 18, F_PXB = 32;
+// image row pitch in pixel slots for a tile 16 NP pixels wide: 20 (18 used) / 36 (34 used).  Any pitch = 4 mod 8 keeps
+// every ds_read_b128 of the pixel operand conflict-free (row stride = 32 banks mod 64; brute-forced for 20, same residue
+// for 36)
+__host__ __device__ constexpr int f_pitch(int np) { return np == 1 ? 20 : 36; }
+__host__ __device__ constexpr int f_lo(int np) { return F_ROWS * f_pitch(np) * F_PXB; }   // byte offset of the lo plane
+__host__ __device__ constexpr int f_w(int np) { return 2 * f_lo(np); }                    // weight planes behind the input planes
 
 __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
-__host__ __device__ constexpr int tap_off(int t) { return ((t / 3) * F_PITCH + (t % 3)) * F_PXB; }
 }  // namespace
 
-template <int NH>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
+// NH: 32-channel blocks per workgroup (64-channel tiles: waves 4-7 own channels 32-63 of the same 16 x 16 pixels).
+// NP: 16-pixel column blocks per workgroup (NP = 2, NH = 1: waves 4-7 own columns 16-31 of a 16 x 32 pixel tile and the
+//     SAME 32 channels: the weight slab — 44 % of a 32-channel tile's staged bytes — is staged once per 512 pixels, and
+//     a CU holds 16 waves (two 512-thread workgroups of 59.5 KB) instead of 12 (three 256-thread ones of 41.5 KB)).
+template <int NH, int NP>
+__global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
+  static_assert(NH * NP <= 2, "one workgroup is 256 or 512 threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   constexpr int NT = NH;                            // 32-channel blocks per workgroup (conv_epilogue.inc)
   constexpr int N = NH * 32, NN = 2;
-  constexpr int THREADS = 256 * NH;
+  constexpr int THREADS = 256 * NH * NP;
   constexpr int WL = 9 * N * 32;                    // byte offset of the wl plane behind the wh plane
   constexpr int KC = 16, Q = 4;
+  constexpr int F_PITCH = f_pitch(NP), F_LO = f_lo(NP), F_W = f_w(NP), TW = TILE * NP;
+  auto tap_off = [](int t) constexpr { return ((t / 3) * F_PITCH + (t % 3)) * F_PXB; };
+  // NP = 2: the weight slab of a chunk (18 KB) is copied global -> LDS by buffer_load ... lds (LDS-DMA, no registers, no
+  // ds_write) into one of TWO slabs, requested a chunk ahead: the 512-thread form has no registers left for a weight
+  // prefetch (it spilled 9-16 at its 128-register budget), and 59.5 + 18 KB still lets two workgroups share a CU.
+  constexpr bool WDMA = NP == 2;
 
   const int tid = threadIdx.x;
   // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL: fp16 conversions that overflow clamp to +-65504
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   const int lane = tid & 63;
-  const int nh = tid >> 8;                          // 32-channel block of this wave
-  // pixel rows 4 wave .. 4 wave + 3.  The second channel block's waves take the row groups rotated by two, so that the
+  const int half = tid >> 8;                        // second half of a 512-thread workgroup: ...
+  const int nh = NP == 1 ? half : 0;                // ... the second 32-channel block of the same pixels (NH = 2)
+  const int ph = NP == 1 ? 0 : half;                // ... or the second 16-pixel column block of the same channels (NP = 2)
+  // pixel rows 4 wave .. 4 wave + 3.  The second half's waves take the row groups rotated by two, so that the
   // two waves of a workgroup that share a SIMD (w and w + 4: waves go to the SIMDs cyclically) own different rows: in
   // the ragged last tile row of a map (below) the waves that still have work are then spread over all four SIMDs.
-  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 2 * nh) & 3);
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 2 * half) & 3);
   // XCD-aware tile order (conv3x3.hip): every XCD gets a contiguous run of tiles
   int bid = blockIdx.x;
   {
@@ -71,13 +88,14 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
-  const int y0 = ty * TILE, x0 = tx * TILE;
+  const int y0 = ty * TILE, x0 = tx * TW;
   const int H = a.H, W = a.W;
   const int n0 = blockIdx.y * N;
   // Ragged last tile row (map height not a multiple of 16: 120 -> 8 valid rows, 60 -> 12, 30 -> 14): a wave whose
   // four rows lie wholly below the map multiplies and stores nothing (it still stages and joins every barrier).
   // H = 120 / 60 otherwise spend 6.25 % of their matrix work on padding rows.
-  const bool busy = y0 + 4 * wave < H;
+  // (and, in a 32-pixel-wide tile that hangs over the right edge, the column block wholly beyond it)
+  const bool busy = y0 + 4 * wave < H && x0 + 16 * ph < W;
 
   f32x4 acc[4][NN];
 #pragma unroll
@@ -87,7 +105,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
 
   // operand read addresses (bytes from the start of LDS); M-tile, tap, N-tile and slot offsets are immediates
   const int lg = lane >> 4, lp = lane & 15;     // k-group and operand row of this lane
-  const int a0 = ((wave * 4 + ((lp >> 1) & 1)) * F_PITCH + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
+  const int a0 = ((wave * 4 + ((lp >> 1) & 1)) * F_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
   const int a_dx = a0 + (lg >> 1) * F_PXB;               // second tap one pixel to the right
   const int a_dy = a0 + (lg >> 1) * F_PITCH * F_PXB;     // second tap one row down
   const int a_s = a0 + (lg >> 1) * F_LO;                 // single tap: k-groups 2, 3 read the lo plane
@@ -104,11 +122,16 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   // (columns 18, 19 are never loaded): granule gi = tid + 256 it lands at byte 8 gi of the hi plane, so the LDS side
   // needs no per-iteration register, and the global side keeps ONE pixel index per iteration — the byte offset into
   // either source is pix * pixel-stride (both are dense NHWC views: row stride = W * pixel stride, checked at launch)
-  constexpr int IN_G = F_ROWS * F_PITCH * Q;
+  // NP = 2 walks only the 34 used columns of a row (2448 granules = 5 per thread; the 36-slot rows would need 6) and
+  // keeps the granule's image slot beside its pixel index: st = slot << 20 | pixel (0xfffff = zero padding; the
+  // launcher keeps H * W below 2^20 for this variant)
+  constexpr int IN_COLS = NP == 1 ? F_PITCH : TW + 2;
+  constexpr int IN_G = F_ROWS * IN_COLS * Q;
   constexpr int IN_IT = (IN_G + THREADS - 1) / THREADS;
+  constexpr int PIX_NONE = 0xfffff;
   constexpr int W_G = 9 * N * Q;                    // weight granules of a chunk
   constexpr int W_IT = (W_G + THREADS - 1) / THREADS;
-  float4 rin[IN_IT], rw[W_IT];
+  float4 rin[IN_IT], rw[WDMA ? 1 : W_IT];
   const int st_q4 = 4 * (tid % Q);
   constexpr int OOB = 0x7ffffff0;
   int st_pix[IN_IT];
@@ -116,10 +139,11 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   for (int it = 0; it < IN_IT; ++it) {
     const int gi = tid + THREADS * it;
     const int hp = gi / Q;
-    const int py = hp / F_PITCH, px = hp - py * F_PITCH;
+    const int py = hp / IN_COLS, px = hp - py * IN_COLS;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool ok = gi < IN_G && px < F_ROWS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    st_pix[it] = ok ? gy * W + gx : -1;
+    const bool ok = gi < IN_G && px < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    if (NP == 1) st_pix[it] = ok ? gy * W + gx : -1;
+    else st_pix[it] = ((py * F_PITCH + px) << 20) | (ok ? gy * W + gx : PIX_NONE);
   }
   const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;      // pixel strides in bytes
   // weight granule gi = tid + THREADS it of a chunk: 16-byte quad q = gi & 3 of row gi >> 2 (row = slot * N + n);
@@ -149,6 +173,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
       for (int it = 0; it < IN_IT; ++it) {
         int pix = st_pix[it];
         asm volatile("" : "+v"(pix));      // keep ONE register per granule: the per-source products must not be hoisted
+        if (NP != 1) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
         const int off = pix < 0 ? OOB : pix * ps + so;
         rin[it] = __builtin_bit_cast(float4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                                    : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
@@ -163,6 +188,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
       for (int it = 0; it < IN_IT; ++it) {
         int pix = st_pix[it];
         asm volatile("" : "+v"(pix));
+        if (NP != 1) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
         const bool pok = cok && pix >= 0;
         const int o0 = (pok && first) ? pix * ps0 + so : OOB;
         const int o1 = (pok && !first) ? pix * ps1 + so : OOB;
@@ -180,15 +206,34 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
       f16x2 h0, h1, l0, l1;
       split2(v.x, v.y, h0, l0);
       split2(v.z, v.w, h1, l1);
-      *reinterpret_cast<f16x4*>(sm + tid * 8 + it * THREADS * 8) = f16x4{h0[0], h0[1], h1[0], h1[1]};
-      *reinterpret_cast<f16x4*>(sm + F_LO + tid * 8 + it * THREADS * 8) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      // image byte of the granule: linear in the granule index (NP = 1), or slot * 32 + 8 * (granule & 3)
+      const int lb = NP == 1 ? tid * 8 + it * THREADS * 8 : (int)((unsigned)st_pix[it] >> 20) * F_PXB + (tid & 3) * 8;
+      *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<f16x4*>(sm + F_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
     }
   };
 
   auto prefetch_w = [&](int ch) {
+    if constexpr (WDMA) {
+      // piece p = wave + 8 j (18 pieces of 1 KiB per chunk): LDS bytes [1024 p, 1024 p + 1024) of slab ch & 1 =
+      // [wh plane | wl plane], each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it)
-      rw[it] = (KP2D_DBG_ON(4) || KP2D_DBG_ON(16)) ? make_float4(0.f, 0.f, 0.f, 0.f) : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + THREADS * it) * 16, 0));
+      for (int j = 0; j < 3; ++j) {
+        const int pc = wv + 8 * j;
+        if (pc < 2 * WL / 1024) {
+          const int o = 1024 * pc + 16 * lane;
+          const int plane = o >= WL ? 1 : 0, o2 = o - plane * WL;
+          const int voff = (o2 >> 5) * 64 + plane * 32 + ((o2 >> 4) & 1) * 16;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + F_W + (ch & 1) * 2 * WL + 1024 * pc),
+                                                   16, voff, ch * W_G * 16, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it)
+        rw[it] = (KP2D_DBG_ON(4) || KP2D_DBG_ON(16)) ? make_float4(0.f, 0.f, 0.f, 0.f) : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, (ch * W_G + THREADS * it) * 16, 0));
+    }
   };
   prefetch_in(0);
   prefetch_w(0);
@@ -196,14 +241,21 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();          // every wave is done reading the previous chunk's LDS images
     if (!KP2D_DBG_ON(2)) commit_in();
+    if constexpr (!WDMA) {
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      if (KP2D_DBG_ON(2)) break;
-      if (it == W_IT - 1 && W_G % THREADS != 0 && tid + THREADS * it >= W_G) continue;
-      *reinterpret_cast<float4*>(sm + w_lds + it * (THREADS / 4) * 32) = rw[it];
+      for (int it = 0; it < W_IT; ++it) {
+        if (KP2D_DBG_ON(2)) break;
+        if (it == W_IT - 1 && W_G % THREADS != 0 && tid + THREADS * it >= W_G) continue;
+        *reinterpret_cast<float4*>(sm + w_lds + it * (THREADS / 4) * 32) = rw[it];
+      }
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's pieces of the chunk's weight slab have landed
     }
     __syncthreads();
+    // (WDMA: slab (ch + 1) & 1 was last read in the matrix phase of chunk ch - 1, which every wave left before the
+    // first barrier of this chunk)
     if (ch + 1 < nchunk) { prefetch_in(ch + 1); prefetch_w(ch + 1); }
+    const int wbo = WDMA ? (ch & 1) * 2 * WL : 0;      // weight slab of this chunk
 
     if (!KP2D_DBG_ON(8) && busy)
 #pragma unroll
@@ -212,7 +264,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
       const bool single = slot == 8;
       const bool dy = slot == 4;
       const int ab = (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(t);
-      const int bb = (single ? b_s : b_p) + slot * N * 32;
+      const int bb = (single ? b_s : b_p) + slot * N * 32 + wbo;
       f16x8 bh[NN], bl[NN];
 #pragma unroll
       for (int n = 0; n < NN; ++n) {
@@ -253,7 +305,8 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
 #define EPI_ACC(m, n, r) acc[m][n][r]
 #define EPI_CH(n) (nh * 32 + (n) * 16 + lp)
 #define EPI_ROW(m, r) (wave * 4 + 2 * ((m) >> 1) + (((r) >> 1) & 1))
-#define EPI_COL(m, r) (8 * ((m) & 1) + 2 * lg + ((r) & 1))
+#define EPI_COL(m, r) (16 * ph + 8 * ((m) & 1) + 2 * lg + ((r) & 1))
+#define EPI_TW TW
 #define EPI_MVALID(m) busy
 #define EPI_THREADS THREADS
 #include "conv_epilogue.inc"
@@ -266,22 +319,25 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 4) void conv3x3_f16x3_kerne
 #undef EPI_ROW
 #undef EPI_COL
 #undef EPI_MVALID
+#undef EPI_TW
 }
 
-template <int NH>
-static int launch_f(const ConvArgs& a, hipStream_t s) {
-  constexpr int N = NH * 32;
-  size_t lds = (size_t)F_W + 2 * 9 * N * 32;
-  const size_t lds_out = (size_t)N * 257 * sizeof(float);
+template <int NH, int NP>
+static int launch_f(const ConvArgs& a0, hipStream_t s) {
+  constexpr int N = NH * 32, TW = TILE * NP;
+  ConvArgs a = a0;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  size_t lds = (size_t)f_w(NP) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
+  const size_t lds_out = (size_t)N * (TILE * TW + 1) * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
-  const size_t lds_tile = (size_t)16 * 16 * N * sizeof(float);
+  const size_t lds_tile = (size_t)TILE * TW * N * sizeof(float);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
   static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH>))) return e;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / N;
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
-  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH>), dim3(grid, groups), dim3(256 * NH), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH, NP>), dim3(grid, groups), dim3(256 * NH * NP), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -292,7 +348,14 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if ((long)a.H * a.W * (a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps) * 4 >= 0x7ffffff0L) return -1002;
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32 || a.ng32;
-  return one ? launch_f<1>(a, s) : launch_f<2>(a, s);
+  if (!one) return launch_f<2, 1>(a, s);
+  // 32-channel layers on grids that fill the chip anyway: 16 x 32 pixel tiles (one weight slab per 512 pixels, 16 waves
+  // per CU).  Small grids keep the 16 x 16 tiles (twice the workgroups, half as long: single frames).  KP2D_WIDE=0: never.
+  static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
+  const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
+  // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)
+  if (wide_on && a.store != ST_NCHW && a.W >= 32 && wide_tiles >= 1024 && (long)a.H * a.W < (1L << 20)) return launch_f<1, 2>(a, s);
+  return launch_f<1, 1>(a, s);
 }
 
 }  // namespace kp2d
