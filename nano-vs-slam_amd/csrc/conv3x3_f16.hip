@@ -35,13 +35,13 @@ namespace kp2d {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int F_ROWS = 18, F_PXB = 32;
+constexpr int F_PXB = 32;
 // image row pitch in pixel slots for a tile 16 NP pixels wide: 20 (18 used) / 36 (34 used).  Any pitch = 4 mod 8 keeps
 // every ds_read_b128 of the pixel operand conflict-free (row stride = 32 banks mod 64; brute-forced for 20, same residue
 // for 36)
 __host__ __device__ constexpr int f_pitch(int np) { return np == 1 ? 20 : 36; }
-__host__ __device__ constexpr int f_lo(int np) { return F_ROWS * f_pitch(np) * F_PXB; }   // byte offset of the lo plane
-__host__ __device__ constexpr int f_w(int np) { return 2 * f_lo(np); }                    // weight planes behind the input planes
+__host__ __device__ constexpr int f_lo(int np, int th) { return (th + 2) * f_pitch(np) * F_PXB; }   // byte offset of the lo plane
+__host__ __device__ constexpr int f_w(int np, int th) { return 2 * f_lo(np, th); }                  // weight planes behind the input planes
 
 __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
 }  // namespace
@@ -50,9 +50,14 @@ __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ?
 // NP: 16-pixel column blocks per workgroup (NP = 2, NH = 1: waves 4-7 own columns 16-31 of a 16 x 32 pixel tile and the
 //     SAME 32 channels: the weight slab — 44 % of a 32-channel tile's staged bytes — is staged once per 512 pixels, and
 //     a CU holds 16 waves (two 512-thread workgroups of 59.5 KB) instead of 12 (three 256-thread ones of 41.5 KB)).
-template <int NH, int NP>
+// TH: tile height, 16 or 8 (NH = NP = 1 only).  TH = 8 is the single-frame form: a wave owns two pixel rows (two M-tiles,
+//     16 accumulators), so a layer of a 60 x 80 map is 80 workgroups of half the length instead of 40 — a frame's ~25
+//     dependent launches are each as long as ONE workgroup's serial chain.
+template <int NH, int NP, int TH>
 __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
   static_assert(NH * NP <= 2, "one workgroup is 256 or 512 threads");
+  static_assert(TH == 16 || (TH == 8 && NH == 1 && NP == 1), "short tiles exist for the 256-thread form only");
+  constexpr int F_ROWS = TH + 2, MT = TH / 4;       // halo rows; M-tiles (2 x 8 pixels) per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   constexpr int NT = NH;                            // 32-channel blocks per workgroup (conv_epilogue.inc)
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   constexpr int THREADS = 256 * NH * NP;
   constexpr int WL = 9 * N * 32;                    // byte offset of the wl plane behind the wh plane
   constexpr int KC = 16, Q = 4;
-  constexpr int F_PITCH = f_pitch(NP), F_LO = f_lo(NP), F_W = f_w(NP), TW = TILE * NP;
+  constexpr int F_PITCH = f_pitch(NP), F_LO = f_lo(NP, TH), F_W = f_w(NP, TH), TW = TILE * NP;
   auto tap_off = [](int t) constexpr { return ((t / 3) * F_PITCH + (t % 3)) * F_PXB; };
   // NP = 2: the weight slab of a chunk (18 KB) is copied global -> LDS by buffer_load ... lds (LDS-DMA, no registers, no
   // ds_write) into one of TWO slabs, requested a chunk ahead: the 512-thread form has no registers left for a weight
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   const int half = tid >> 8;                        // second half of a 512-thread workgroup: ...
   const int nh = NP == 1 ? half : 0;                // ... the second 32-channel block of the same pixels (NH = 2)
   const int ph = NP == 1 ? 0 : half;                // ... or the second 16-pixel column block of the same channels (NP = 2)
-  // pixel rows 4 wave .. 4 wave + 3.  The second half's waves take the row groups rotated by two, so that the
+  // pixel rows MT wave .. MT wave + MT - 1 (MT = 4: two row pairs x two 8-pixel column halves).  The second half's waves take the row groups rotated by two, so that the
   // two waves of a workgroup that share a SIMD (w and w + 4: waves go to the SIMDs cyclically) own different rows: in
   // the ragged last tile row of a map (below) the waves that still have work are then spread over all four SIMDs.
   const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 2 * half) & 3);
@@ -88,24 +93,24 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
-  const int y0 = ty * TILE, x0 = tx * TW;
+  const int y0 = ty * TH, x0 = tx * TW;
   const int H = a.H, W = a.W;
   const int n0 = blockIdx.y * N;
   // Ragged last tile row (map height not a multiple of 16: 120 -> 8 valid rows, 60 -> 12, 30 -> 14): a wave whose
   // four rows lie wholly below the map multiplies and stores nothing (it still stages and joins every barrier).
   // H = 120 / 60 otherwise spend 6.25 % of their matrix work on padding rows.
   // (and, in a 32-pixel-wide tile that hangs over the right edge, the column block wholly beyond it)
-  const bool busy = y0 + 4 * wave < H && x0 + 16 * ph < W;
+  const bool busy = y0 + MT * wave < H && x0 + 16 * ph < W;
 
-  f32x4 acc[4][NN];
+  f32x4 acc[MT][NN];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // operand read addresses (bytes from the start of LDS); M-tile, tap, N-tile and slot offsets are immediates
   const int lg = lane >> 4, lp = lane & 15;     // k-group and operand row of this lane
-  const int a0 = ((wave * 4 + ((lp >> 1) & 1)) * F_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
+  const int a0 = ((wave * MT + ((lp >> 1) & 1)) * F_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
   const int a_dx = a0 + (lg >> 1) * F_PXB;               // second tap one pixel to the right
   const int a_dy = a0 + (lg >> 1) * F_PITCH * F_PXB;     // second tap one row down
   const int a_s = a0 + (lg >> 1) * F_LO;                 // single tap: k-groups 2, 3 read the lo plane
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
         bl[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512 + WL);
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const int mo = (2 * (m >> 1) * F_PITCH + 8 * (m & 1)) * F_PXB;
         if (single) {
           // k-groups 0, 1 carry xh, groups 2, 3 xl of the same tap: both weight halves see both operand halves
@@ -299,14 +304,15 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   constexpr int EPI_ROUNDS = 1;
   constexpr bool EPI_GELU = false;
   // accumulator layout of the 16x16 MFMA tiles (conv_epilogue.inc): lane (lp, lg), M-tile m, register r
-#define EPI_NM 4
+#define EPI_NM MT
 #define EPI_NN NN
 #define EPI_R 4
 #define EPI_ACC(m, n, r) acc[m][n][r]
 #define EPI_CH(n) (nh * 32 + (n) * 16 + lp)
-#define EPI_ROW(m, r) (wave * 4 + 2 * ((m) >> 1) + (((r) >> 1) & 1))
+#define EPI_ROW(m, r) (wave * MT + 2 * ((m) >> 1) + (((r) >> 1) & 1))
 #define EPI_COL(m, r) (16 * ph + 8 * ((m) & 1) + 2 * lg + ((r) & 1))
 #define EPI_TW TW
+#define EPI_TH TH
 #define EPI_MVALID(m) busy
 #define EPI_THREADS THREADS
 #include "conv_epilogue.inc"
@@ -320,24 +326,26 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 #undef EPI_COL
 #undef EPI_MVALID
 #undef EPI_TW
+#undef EPI_TH
 }
 
-template <int NH, int NP>
+template <int NH, int NP, int TH = TILE>
 static int launch_f(const ConvArgs& a0, hipStream_t s) {
   constexpr int N = NH * 32, TW = TILE * NP;
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
-  size_t lds = (size_t)f_w(NP) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
-  const size_t lds_out = (size_t)N * (TILE * TW + 1) * sizeof(float);
+  a.tiles_y = (a.H + TH - 1) / TH;
+  size_t lds = (size_t)f_w(NP, TH) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
+  const size_t lds_out = (size_t)N * (TH * TW + 1) * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
-  const size_t lds_tile = (size_t)TILE * TW * N * sizeof(float);
+  const size_t lds_tile = (size_t)TH * TW * N * sizeof(float);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
   static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP>))) return e;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP, TH>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / N;
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
-  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH, NP>), dim3(grid, groups), dim3(256 * NH * NP), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH, NP, TH>), dim3(grid, groups), dim3(256 * NH * NP), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -355,6 +363,9 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
   // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)
   if (wide_on && a.store != ST_NCHW && a.W >= 32 && wide_tiles >= 1024 && (long)a.H * a.W < (1L << 20)) return launch_f<1, 2>(a, s);
+  // single frames (the grid of 16 x 16 tiles would leave most CUs idle): 8-row tiles, twice the workgroups, half as long
+  static const bool short_on = !(getenv("KP2D_SHORT") && getenv("KP2D_SHORT")[0] == '0');
+  if (short_on && (long)a.tiles_x * a.tiles_y * a.B * (a.npad / 32) < 256) return launch_f<1, 1, 8>(a, s);
   return launch_f<1, 1>(a, s);
 }
 
