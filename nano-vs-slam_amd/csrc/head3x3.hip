@@ -4,101 +4,103 @@
 //
 // On the matrix cores these layers compute a 32-channel tile for 1-3 real channels (9.6 / 18.6 TFLOP/s,
 // profiles/r2_layers.txt).  They are HBM-bound dot products: 4 * Cin bytes read per pixel for 18 * Cin * Cout FLOP.
-// Here a workgroup stages the 18 x 18 halo tile of a 16 x 16 pixel tile in 16-channel chunks (fp32, 80-byte pixel
-// pitch), a thread owns one pixel, and the weights reach the FMAs as scalar operands (uniform index -> s_load), as
-// in conv1a.  Exact fp32 arithmetic in both precision modes.
+// A workgroup owns a 4 x 16 pixel tile: it stages the 6 x 18 halo of up to 64 input channels (fp32; 68-float pixel
+// pitch and 1280-float row pitch: brute-forced over the ds_read_b128 lane groups, every operand read is bank-conflict
+// free), and WAVE c multiplies 16-channel chunk c for all 64 pixels (lane = pixel), so the weights of a wave are uniform
+// and reach the FMAs as scalar operands (s_load), as in conv1a.  The four partial sums of a pixel meet in LDS and are added in chunk order — one fixed order whatever the
+// batch or grid size, so results do not depend on either.  Exact fp32 arithmetic in both precision modes.
+// (First version: 16 x 16 tiles, a thread walked all chunks of its pixel: at one frame its 20 workgroups were 17-19 us
+// serial chains, slower than the matrix-core kernel it replaced.)
 #include "conv_common.h"
 
 namespace kp2d {
 
 namespace {
-constexpr int HD_KC = 16, HD_HP = 18, HD_PITCH = HD_KC + 4;
-constexpr int HD_G = HD_HP * HD_HP * (HD_KC / 4);          // float4 granules of a chunk's halo tile
+constexpr int HD_TY = 4, HD_TX = 16, HD_HY = HD_TY + 2, HD_HX = HD_TX + 2;      // tile and halo, rows x columns
+constexpr int HD_SC = 64, HD_PITCH = HD_SC + 4, HD_ROW = 1280;                  // channels staged at a time; LDS pitches (floats)
+constexpr int HD_G = HD_HY * HD_HX * (HD_SC / 4);     // float4 granules of a staged super-chunk (1728)
 constexpr int HD_IT = (HD_G + 255) / 256;
 }  // namespace
 
 // a.w: [chunk][tap][4][16] floats (kp2d_api.cpp pack(): ConvPack::wd_off), a.scale / a.shift: [cout]
 template <int CO>
 __global__ __launch_bounds__(256) void head3x3_kernel(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_in[HD_HP * HD_HP * HD_PITCH];
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_in[HD_HY * HD_ROW];             // 30,720 B
+  __shared__ float s_part[4 * CO * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
-  const int y0 = ty * TILE, x0 = tx * TILE;
+  const int y0 = ty * HD_TY, x0 = tx * HD_TX;
   const int H = a.H, W = a.W;
-  const int nchunk = (a.cin + HD_KC - 1) / HD_KC;
+  const int nchunk = (a.cin + 15) >> 4;
 
   const float* src = a.in0.p + (size_t)b * a.in0.bs + a.in0.o;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(src), 0, (int)((a.in0.bs - a.in0.o) * 4), 0x00020000);
   constexpr int OOB = 0x7ffffff0;
   const int ps = (int)a.in0.ps * 4;
-  const int q4 = 4 * (tid & 3);
-  int st_off[HD_IT];          // byte offset of this thread's granule in the source (chunk 0), OOB for the zero padding
-#pragma unroll
-  for (int it = 0; it < HD_IT; ++it) {
-    const int g = tid + 256 * it, hp = g >> 2;
-    const int py = hp / HD_HP, px = hp - py * HD_HP;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool ok = g < HD_G && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    st_off[it] = ok ? (gy * W + gx) * ps + q4 * 4 : OOB;
-  }
-  float4 r[HD_IT];
-  auto prefetch = [&](int ch) {
-    const bool cok = ch * HD_KC + q4 < a.cin;       // channel tail of a last, partial chunk
-#pragma unroll
-    for (int it = 0; it < HD_IT; ++it) {
-      const int off = (cok && st_off[it] != OOB) ? st_off[it] + ch * HD_KC * 4 : OOB;
-      r[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    }
-  };
+  const int q4 = 4 * (tid & 15);                    // first channel (within the super-chunk) of this thread's granules
 
   float acc[CO];
 #pragma unroll
   for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-  const int ly = tid >> 4, lx = tid & 15;
+  const int ly = lane >> 4, lx = lane & 15;
   const float* __restrict__ wg = a.w;
 
-  prefetch(0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();
+  for (int sc = 0; sc * HD_SC < a.cin; ++sc) {
+    if (sc) __syncthreads();
+    // stage the halo of channels [64 sc, 64 sc + 64): granule = 4 channels of one halo pixel
+    const bool cok = sc * HD_SC + q4 < a.cin;
 #pragma unroll
     for (int it = 0; it < HD_IT; ++it) {
-      const int g = tid + 256 * it;
+      const int g = tid + 256 * it, hp = g >> 4;
       if (it == HD_IT - 1 && g >= HD_G) continue;
-      *reinterpret_cast<float4*>(&s_in[(g >> 2) * HD_PITCH + q4]) = r[it];
+      const int py = hp / HD_HX, px = hp - py * HD_HX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = cok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int off = ok ? (gy * W + gx) * ps + (sc * HD_SC + q4) * 4 : OOB;
+      *reinterpret_cast<float4*>(&s_in[py * HD_ROW + px * HD_PITCH + q4]) =
+          __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
     __syncthreads();
-    if (ch + 1 < nchunk) prefetch(ch + 1);
+    const int ch = sc * 4 + wave;                   // this wave's 16-channel chunk
+    if (ch < nchunk) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* sp = &s_in[((ly + tap / 3) * HD_HP + lx + tap % 3) * HD_PITCH];
-      const float* wt = wg + ((size_t)ch * 9 + tap) * 4 * HD_KC;      // uniform: scalar loads
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* sp = &s_in[(ly + tap / 3) * HD_ROW + (lx + tap % 3) * HD_PITCH + wave * 16];
+        const float* wt = wg + ((size_t)ch * 9 + tap) * 4 * 16;      // wave-uniform: scalar loads
 #pragma unroll
-      for (int q = 0; q < HD_KC / 4; ++q) {
-        const float4 x = *reinterpret_cast<const float4*>(sp + 4 * q);
+        for (int q = 0; q < 4; ++q) {
+          const float4 x = *reinterpret_cast<const float4*>(sp + 4 * q);
 #pragma unroll
-        for (int c = 0; c < CO; ++c) {
-          acc[c] = fmaf(x.x, wt[c * HD_KC + 4 * q + 0], acc[c]);
-          acc[c] = fmaf(x.y, wt[c * HD_KC + 4 * q + 1], acc[c]);
-          acc[c] = fmaf(x.z, wt[c * HD_KC + 4 * q + 2], acc[c]);
-          acc[c] = fmaf(x.w, wt[c * HD_KC + 4 * q + 3], acc[c]);
+          for (int c = 0; c < CO; ++c) {
+            acc[c] = fmaf(x.x, wt[c * 16 + 4 * q + 0], acc[c]);
+            acc[c] = fmaf(x.y, wt[c * 16 + 4 * q + 1], acc[c]);
+            acc[c] = fmaf(x.z, wt[c * 16 + 4 * q + 2], acc[c]);
+            acc[c] = fmaf(x.w, wt[c * 16 + 4 * q + 3], acc[c]);
+          }
         }
       }
     }
   }
-
+  // the four chunk-lanes of a pixel, added in chunk order by wave 0
+#pragma unroll
+  for (int c = 0; c < CO; ++c) s_part[(wave * CO + c) * 64 + lane] = acc[c];
+  __syncthreads();
+  if (wave != 0) return;
   const int y = y0 + ly, x = x0 + lx;
   if (y < H && x < W) {
     const size_t plane = (size_t)H * W;
     const int ns = a.nsplit;
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
-      float v = fmaf(acc[c], a.scale[c], a.shift[c]);
-      if (a.act == ACT_SOFTMAX_C) continue;   // (not a head activation; launch_head3x3 refuses it)
+      const float sum = ((s_part[(0 * CO + c) * 64 + lane] + s_part[(1 * CO + c) * 64 + lane]) + s_part[(2 * CO + c) * 64 + lane]) +
+                        s_part[(3 * CO + c) * 64 + lane];
+      float v = fmaf(sum, a.scale[c], a.shift[c]);
       if (a.act != ACT_NONE) v = act_apply(v, a.act, c);
       float* dst = (c < ns) ? a.out0 + ((size_t)b * ns + c) * plane
                             : a.out1 + ((size_t)b * (a.cout - ns) + (c - ns)) * plane;
@@ -107,10 +109,13 @@ __global__ __launch_bounds__(256) void head3x3_kernel(const ConvArgs a) {
   }
 }
 
-int launch_head3x3(const ConvArgs& a, hipStream_t s) {
-  if (a.taps != 9 || a.cout < 1 || a.cout > 4 || a.store != ST_NCHW || a.in1.c != 0 || a.act == ACT_SOFTMAX_C) return -1000;
-  if (a.in0.rs != (long)a.W * a.in0.ps) return -1004;
-  if ((long)a.H * a.W * a.in0.ps * 4 >= 0x7ffffff0L) return -1002;
+int launch_head3x3(const ConvArgs& a0, hipStream_t s) {
+  if (a0.taps != 9 || a0.cout < 1 || a0.cout > 4 || a0.store != ST_NCHW || a0.in1.c != 0 || a0.act == ACT_SOFTMAX_C) return -1000;
+  if (a0.in0.rs != (long)a0.W * a0.in0.ps) return -1004;
+  if ((long)a0.H * a0.W * a0.in0.ps * 4 >= 0x7ffffff0L) return -1002;
+  ConvArgs a = a0;
+  a.tiles_x = (a.W + HD_TX - 1) / HD_TX;
+  a.tiles_y = (a.H + HD_TY - 1) / HD_TY;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B);
   switch (a.cout) {
     case 1: hipLaunchKernelGGL((head3x3_kernel<1>), grid, dim3(256), 0, s, a); break;

@@ -171,6 +171,11 @@ struct LgTailArgs {
   const float* ln_g; const float* ln_b;  // ffn.1
   const float* w2; const float* b2;      // ffn.3: W^T [2D][D], bias
   int rows, D;
+  // optional: the NEXT token-wise projection of the updated x in the same launch (the cross block's [to_qk | to_v], the
+  // next layer's Wqkv with its rotary epilogue, or the final projection): out[row][0..nvalid) = x W^T + b
+  const float* wn = nullptr; const float* bn = nullptr;   // W^T [D][nn] (nn = 64 or 96, padded), bias [nn]
+  float* on = nullptr; int nn = 0, nos = 0, nvalid = 0;   // output, its row stride, columns stored
+  const float* cs = nullptr; int hd = 0, rot_cols = 0;    // rotary: per-row cos | sin, head dim, leading columns that rotate
 };
 int launch_lg_tail(const LgTailArgs& a, hipStream_t s);
 

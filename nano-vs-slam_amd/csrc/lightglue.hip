@@ -294,11 +294,14 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
       }
     }
   }
-  __syncthreads();                 // every thread is done reading (x | message)^T
+  __syncthreads();                 // every thread is done reading (x | message)^T and W1
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + 4 * rg + r] = h[r][c];
+  // the next projection's weights take W1's place (D x nn <= 32 x 96 floats)
+  if (a.nn)
+    for (int e = tid; e < (D * a.nn) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.wn)[e];
   __syncthreads();
   // ---- stage 3: x += h W2^T + b2 ----
   {
@@ -314,17 +317,74 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + 4 * rg + r;
+      float2 nx = make_float2(0.f, 0.f);
       if (row < a.rows) {
         float2* xp = reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg);
         const float2 old = *xp;
-        *xp = make_float2(old.x + acc[r][0] + b0, old.y + acc[r][1] + b1);
+        nx = make_float2(old.x + acc[r][0] + b0, old.y + acc[r][1] + b1);
+        *xp = nx;
+      }
+      if (a.nn) {                    // updated x, transposed, for stage 4 (ctx^T is no longer needed)
+        ct[(2 * cg) * R + 4 * rg + r] = nx.x;
+        ct[(2 * cg + 1) * R + 4 * rg + r] = nx.y;
       }
     }
+  }
+  if (!a.nn) return;
+  __syncthreads();
+  // ---- stage 4: the next projection of the updated rows (same arithmetic and order as lg_linear_kernel) ----
+  {
+    const int nn = a.nn, nj = nn >> 5;
+    float acc[4][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[r][c] = 0.f;
+    for (int k = 0; k < D; ++k) {
+      const float4 xv = *reinterpret_cast<const float4*>(&ct[k * R + 4 * rg]);
+      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (j < nj) {
+          const float2 wv = *reinterpret_cast<const float2*>(&w1[k * nn + 2 * cg + 32 * j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[r][2 * j] = fmaf(xr[r], wv.x, acc[r][2 * j]);
+            acc[r][2 * j + 1] = fmaf(xr[r], wv.y, acc[r][2 * j + 1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j < nj) {
+        const int c = 2 * cg + 32 * j;
+        const float b0 = a.bn ? a.bn[c] : 0.f, b1 = a.bn ? a.bn[c + 1] : 0.f;
+        const bool rot = a.cs && c < a.rot_cols;
+        const int hf = a.hd >> 1, f = rot ? (c % a.hd) >> 1 : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + 4 * rg + r;
+          if (row >= a.rows || c >= a.nvalid) continue;
+          float y0 = acc[r][2 * j] + b0, y1 = acc[r][2 * j + 1] + b1;
+          if (rot) {
+            const float co = a.cs[(size_t)row * a.hd + f], si = a.cs[(size_t)row * a.hd + hf + f];
+            const float t0 = y0, t1 = y1;
+            y0 = t0 * co - t1 * si;
+            y1 = t1 * co + t0 * si;
+          }
+          float* o = a.on + (size_t)row * a.nos + c;
+          o[0] = y0;
+          if (c + 1 < a.nvalid) o[1] = y1;
+        }
+      }
   }
 }
 
 int launch_lg_tail(const LgTailArgs& a, hipStream_t s) {
   if (a.D != 32) return -1804;
+  if (a.nn && (a.nn != 64 && a.nn != 96)) return -1805;
+  if (a.nn && (!a.wn || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.cs && ((a.hd & 1) || (a.rot_cols & 1))))) return -1805;
   const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + 32 * LG_ROWS + 64 * LG_ROWS) * sizeof(float);
   hipLaunchKernelGGL(lg_tail_kernel, dim3((a.rows + LG_ROWS - 1) / LG_ROWS), dim3(256), lds, s, a);
   return (int)hipGetLastError();

@@ -315,13 +315,23 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
   };
   // D = 32 (configs S, A): out_proj / to_out + ffn + residual as ONE row-local kernel (lightglue.hip lg_tail_kernel)
   static const bool fuse_tail = !(getenv("KP2D_LG_FUSE") && getenv("KP2D_LG_FUSE")[0] == '0');
-  auto tail = [&](const Lin& proj, const Ffn& f, const char* what) -> int {
+  // `next`: the token-wise projection that follows the block (the cross block's [to_qk | to_v], the next layer's Wqkv
+  // with rotary, the final projection) runs in the tail's launch on the rows it has just updated: 8 launches fewer
+  // per forward than one lg_linear per projection (the matcher is a chain of ~35 dependent launches of ~10 us)
+  static const bool fuse_next = !(getenv("KP2D_LG_FUSE_NEXT") && getenv("KP2D_LG_FUSE_NEXT")[0] == '0');
+  auto tail = [&](const Lin& proj, const Ffn& f, const char* what, const Lin* next, float* nout, int nos, int nvalid,
+                  bool rotary) -> int {
     LgTailArgs t{};
     t.x = X; t.ctx = CTX; t.wo = blob + proj.w; t.bo = blob + proj.b; t.w1 = blob + f.l0.w; t.b1 = blob + f.l0.b;
     t.ln_g = blob + f.g; t.ln_b = blob + f.be; t.w2 = blob + f.l3.w; t.b2 = blob + f.l3.b; t.rows = R; t.D = d;
+    if (next) {
+      t.wn = blob + next->w; t.bn = blob + next->b; t.on = nout; t.nn = next->nout; t.nos = nos; t.nvalid = nvalid;
+      if (rotary) { t.cs = CS; t.hd = hd; t.rot_cols = 2 * d; }
+    }
     LG_CHECK(launch_lg_tail(t, st), what);
     return KP2D_OK;
   };
+  const bool fused = fuse_tail && fuse_next && d == 32;
   const float scale = 1.f / std::sqrt((float)hd);
   for (int i = 0; i < m->cfg.n_layers; ++i) {
     const Layer& L = m->layers[i];
@@ -329,7 +339,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     {
       LgLinArgs a = linear(L.qkv, X, d, d, nullptr, 0, 0, T3, 3 * d, R, 3 * d, LG_EPI_ROTARY);
       a.cs = CS; a.hd = hd; a.rot_cols = 2 * d;
-      LG_CHECK(launch_lg_linear(a, st), "self_attn.Wqkv");
+      if (!(fused && i > 0)) LG_CHECK(launch_lg_linear(a, st), "self_attn.Wqkv");      // (i > 0: done by the previous tail)
       if (M == N) {   // both images as one batch of 2B sequences
         AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
         t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d; t.prec = 1;
@@ -345,7 +355,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         }
       }
       if (fuse_tail && d == 32) {
-        int rc = tail(L.out_proj, L.fs, "self_attn tail");
+        int rc = tail(L.out_proj, L.fs, "self_attn tail", fused ? &L.qkv_x : nullptr, T3, 2 * d, 2 * d, false);
         if (rc != KP2D_OK) return rc;
       } else {
         a = linear(L.out_proj, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
@@ -357,7 +367,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     // ---- CrossBlock (lightglue.py:303-327): [to_qk | to_v] in one layer, attention both ways ----
     {
       LgLinArgs a = linear(L.qkv_x, X, d, d, nullptr, 0, 0, T3, 2 * d, R, 2 * d, LG_EPI_NONE);
-      LG_CHECK(launch_lg_linear(a, st), "cross_attn.to_qk/to_v");
+      if (!fused) LG_CHECK(launch_lg_linear(a, st), "cross_attn.to_qk/to_v");
       if (M == N) {   // both directions in one launch: sequence b attends to sequence (b + B) mod 2B
         AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
         t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d; t.prec = 1;
@@ -373,7 +383,10 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         }
       }
       if (fuse_tail && d == 32) {
-        int rc = tail(L.to_out, L.fc, "cross_attn tail");
+        const bool last = i + 1 == m->cfg.n_layers;
+        const Lin* nx = !fused ? nullptr : (last ? &m->final : &m->layers[i + 1].qkv);
+        int rc = last ? tail(L.to_out, L.fc, "cross_attn tail", nx, FZ, d + 32, d + 1, false)
+                      : tail(L.to_out, L.fc, "cross_attn tail", nx, T3, 3 * d, 3 * d, true);
         if (rc != KP2D_OK) return rc;
       } else {
         a = linear(L.to_out, CTX, d, d, nullptr, 0, 0, MSG, d, R, d, LG_EPI_NONE);
@@ -385,7 +398,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
   }
   {
     LgLinArgs a = linear(m->final, X, d, d, nullptr, 0, 0, FZ, d + 32, R, d + 1, LG_EPI_NONE);
-    LG_CHECK(launch_lg_linear(a, st), "log_assignment.final_proj");
+    if (!fused || m->cfg.n_layers == 0) LG_CHECK(launch_lg_linear(a, st), "log_assignment.final_proj");
     LgAssignArgs g{};
     g.fz = FZ; g.fs = d + 32; g.D = d; g.B = B; g.M = M; g.N = N; g.scores = log_assignment;
     g.rlse = F(w.rlse); g.clse = F(w.clse); g.max0 = F(w.max0);

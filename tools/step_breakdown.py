@@ -2,8 +2,9 @@
 """Wall time of the bench step's parts in the bench setting (two lanes, 64 frames 240x320): forward only,
 forward + post_processing, and the full step (+ top-k selection and gather).
 
-    python3 tools/step_breakdown.py
+    python3 tools/step_breakdown.py [--batch B]
 """
+import argparse
 import os
 import sys
 import time
@@ -19,7 +20,10 @@ m = tiny_factory("S", 28)
 sd = spread_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
 m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
 m = m.to("cuda:0").eval(); m.training = False
-x = torch.rand(64, 3, 240, 320, device="cuda:0") * 2 - 1
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--batch", type=int, default=64)
+B = _ap.parse_args().batch
+x = torch.rand(B, 3, 240, 320, device="cuda:0") * 2 - 1
 def fwd(): return m(x)
 def full():
     out = m.post_processing(m(x), 240, 320)
