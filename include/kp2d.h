@@ -167,7 +167,8 @@ int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** 
                      double* bytes);
 /* Arithmetic of the convolution kernels (both accumulate in fp32 and meet the 1e-3 / index-identity bar):
  *   KP2D_PREC_FP32   exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain)
- *   KP2D_PREC_F16X3  split fp16: x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16, fp32-grade error
+ *   KP2D_PREC_F16X3  split fp16: x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16 (3x3 convolutions; the 1x1
+ *                    convolutions and the attention kernel use v_mfma_f32_32x32x16_f16), fp32 accumulate, fp32-grade error
  *                    (default; see DESIGN.md "Numerics").  Both weight packs are resident; switching is free. */
 #define KP2D_PREC_FP32 0
 #define KP2D_PREC_F16X3 1

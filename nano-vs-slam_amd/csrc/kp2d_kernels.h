@@ -45,7 +45,7 @@ struct ConvArgs {
   int act, store, nsplit;
   int tiles_x, tiles_y;
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
-  int dbg;                            // timing ablations only (KP2D_DBG): 1 skip stores, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA
+  int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
 
 struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC out, Cin = 3 (RGB) or 1 (use_color=False)

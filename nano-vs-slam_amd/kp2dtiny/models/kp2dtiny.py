@@ -98,7 +98,14 @@ def tiny_factory(config, n_classes, to_mcu=False, to_export=False, v3=False):
 # as a whole single-frame step on the GPU — so the model keeps the list of its tensors and only walks the module tree
 # again after something could have REPLACED a tensor: a parameter / buffer registration anywhere (global torch hooks),
 # or an ``_apply`` (.to / .cuda / .float ...) on any holder.  Both bump this epoch.
+# Supported ways to change weights, all seen on the next call: ``load_state_dict``, in-place writes (``p.add_()``,
+# ``p.copy_()``, ``p.data.copy_()``), ``p.data = t`` (the signature includes every tensor's data pointer), ``setattr`` /
+# ``register_parameter`` / ``register_buffer``, ``.to()`` / ``.float()``.  Writing into ``module._parameters[...]`` or
+# ``module._buffers[...]`` behind torch's back is seen at the latest ``_SIG_RECHECK`` calls later (the cached tensor list
+# is rebuilt from the module tree that often as a self-check).  The hooks below are process-global by torch's design;
+# all they do is increment this counter.
 _STRUCT_EPOCH = [0]
+_SIG_RECHECK = 16
 
 
 def _bump_epoch(*_a, **_k):
@@ -395,10 +402,12 @@ class _KP2DTinyBase(nn.Module):
 
     def _weights_signature(self):
         cache = self.__dict__.get("_sig_cache")
-        if cache is None or cache[0] != _STRUCT_EPOCH[0]:
+        n = self.__dict__.get("_sig_calls", 0) + 1
+        self.__dict__["_sig_calls"] = n
+        if cache is None or cache[0] != _STRUCT_EPOCH[0] or n % _SIG_RECHECK == 0:
             cache = (_STRUCT_EPOCH[0], list(self.state_dict(keep_vars=True).values()))
             self.__dict__["_sig_cache"] = cache
-        return tuple((id(t), t._version) for t in cache[1])
+        return tuple((id(t), t._version, t.data_ptr()) for t in cache[1])
 
     def _warn_if_training_semantics_expected(self):
         """The reference runs BatchNorm on batch statistics and applies Dropout2d while its sub-modules are in training

@@ -318,6 +318,28 @@ def test_weight_updates_and_packed_roundtrip():
         assert torch.equal(other(x)["vlad"], model(x)["vlad"])
 
 
+def test_weight_replacement_paths_are_seen():
+    """Every way a caller may change a weight reaches the engine (kp2dtiny.py, "Supported ways to change weights"):
+    ``p.data = t`` and ``setattr`` on the next call; a write into ``module._parameters`` behind torch's back at the
+    latest ``_SIG_RECHECK`` calls later (the cached tensor list is rebuilt that often)."""
+    from nano_vs_slam_amd.kp2dtiny.models import kp2dtiny as K
+    model, _ = product_model("S", False, 28)
+    x = torch.from_numpy(synthetic_frames(1, 32, 32, seed=3)).to(DEV)
+    with torch.no_grad():
+        a = model(x)["score"].clone()
+        bias = model.score_head.convDb.bias
+        bias.data = bias.data + 0.5                                            # new storage, same Parameter object
+        b = model(x)["score"].clone()
+        assert not torch.equal(a, b)
+        model.score_head.convDb.bias = torch.nn.Parameter(bias.data - 0.5)     # setattr: registration hook
+        assert torch.equal(model(x)["score"], a)
+        model.score_head.convDb._parameters["bias"] = torch.nn.Parameter(bias.data + 1.0)   # behind torch's back
+        seen = False
+        for _ in range(K._SIG_RECHECK + 1):
+            seen = seen or not torch.equal(model(x)["score"], a)
+        assert seen
+
+
 def test_argument_errors():
     model, _ = product_model("S", False, 28)
     with pytest.raises(ValueError):

@@ -12,7 +12,7 @@ mkdir -p "$(dirname "$OUT")"; : > "$OUT"
 for round in 1 2 3; do
   for lib in "$@"; do
     if [ "$lib" = default ]; then unset KP2D_LIB; else export KP2D_LIB="$PWD/$lib"; fi
-    line=$(timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 "${FLAGS[@]}" 2>/dev/null | tail -1)
+    line=$(timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 "${FLAGS[@]}" 2>>"${OUT%.jsonl}.err" | tail -1)
     echo "{\"lib\": \"$lib\", \"round\": $round, \"line\": $line}" >> "$OUT"
     python3 - "$lib" "$line" <<'PY'
 import json, sys

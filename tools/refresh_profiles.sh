@@ -7,9 +7,13 @@ OUT=${1:-gpurun_out/refresh}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "[refresh] $*"; }
+# stderr of every GPU step goes to $OUT/<step>.err (never /dev/null): a fault or abort in a profiling step leaves its message there
+ERRN=0
+errf() { ERRN=$((ERRN + 1)); echo "$OUT/step_${ERRN}.err"; }
 
 step "bench line"
-timeout -k 10 300 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench.json"
+timeout -k 10 300 python3 bench.py 2>"$(errf)" | tail -1 > "$OUT/bench.json"
+timeout -k 10 300 python3 bench.py --steps 1000 --no-cpu-baseline --no-precision-modes 2>"$(errf)" | tail -1 > "$OUT/bench_sustained_1000steps.json"
 cat "$OUT/bench.json" | cut -c1-200
 
 step "rocprofv3 kernel stats, default two lanes"
@@ -19,15 +23,20 @@ KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format 
 find "$OUT/stats1" "$OUT/stats2" -name "*kernel_trace.csv" -delete      # only the --stats summaries are kept
 
 step "per-layer table"
-timeout -k 10 200 python3 tools/layer_profile.py > "$OUT/layers.txt" 2>/dev/null
+timeout -k 10 200 python3 tools/layer_profile.py > "$OUT/layers.txt" 2>"$(errf)"
 head -3 "$OUT/layers.txt"
 
 step "PMC passes"
 tools/pmc_collect.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
+python3 tools/pmc_summarize.py "$OUT/pmc" > "$OUT/pmc_summary.txt" 2>"$(errf)"
+python3 tools/pmc_traffic.py "$OUT/pmc" "$OUT/traffic.json" > /dev/null 2>"$(errf)"
+tools/pmc_collect.sh "$OUT/pmc_cfg4" --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32 > "$OUT/pmc_cfg4.log" 2>&1
+python3 tools/pmc_summarize.py "$OUT/pmc_cfg4" > "$OUT/pmc_cfg4_summary.txt" 2>"$(errf)"
+find "$OUT/pmc" "$OUT/pmc_cfg4" -name "*.csv" -delete      # only the summaries are kept
 
 step "sweep"
 : > "$OUT/sweep.jsonl"
-sweep() { timeout -k 10 300 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> "$OUT/sweep.jsonl"; tail -1 "$OUT/sweep.jsonl" | cut -c60-100; }
+sweep() { timeout -k 10 300 python3 bench.py --no-cpu-baseline "$@" 2>"$(errf)" | tail -1 >> "$OUT/sweep.jsonl"; tail -1 "$OUT/sweep.jsonl" | cut -c60-100; }
 sweep --height 120 --width 160
 sweep
 sweep --batch 32
@@ -35,15 +44,15 @@ sweep --height 480 --width 640 --batch 32
 sweep --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32
 sweep --config S_A --v3
 sweep --config N
-sweep --batch 1 --steps 200
+sweep --batch 1 --steps 300
 sweep --precision fp32
 step "LightGlue"
-timeout -k 10 200 python3 tools/bench_lightglue.py 2>/dev/null | tail -1 > "$OUT/lightglue.jsonl"
-timeout -k 10 200 python3 tools/bench_lightglue.py --pairs 1 2>/dev/null | tail -1 >> "$OUT/lightglue.jsonl"
+timeout -k 10 200 python3 tools/bench_lightglue.py 2>"$(errf)" | tail -1 > "$OUT/lightglue.jsonl"
+timeout -k 10 200 python3 tools/bench_lightglue.py --pairs 1 2>"$(errf)" | tail -1 >> "$OUT/lightglue.jsonl"
 cut -c1-200 "$OUT/lightglue.jsonl"
 step "PCIe-inclusive front-end"
-timeout -k 10 200 python3 tools/bench_frontend.py 2>/dev/null | tail -1 > "$OUT/frontend.jsonl"
-timeout -k 10 200 python3 tools/bench_frontend.py --pinned 2>/dev/null | tail -1 >> "$OUT/frontend.jsonl"
-timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 200 2>/dev/null | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py 2>"$(errf)" | tail -1 > "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --pinned 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 cut -c1-200 "$OUT/frontend.jsonl"
 step done
