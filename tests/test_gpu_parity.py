@@ -328,12 +328,13 @@ def test_weight_replacement_paths_are_seen():
     with torch.no_grad():
         a = model(x)["score"].clone()
         bias = model.score_head.convDb.bias
-        bias.data = bias.data + 0.5                                            # new storage, same Parameter object
+        orig = bias.data.clone()
+        bias.data = orig + 0.5                                                 # new storage, same Parameter object
         b = model(x)["score"].clone()
         assert not torch.equal(a, b)
-        model.score_head.convDb.bias = torch.nn.Parameter(bias.data - 0.5)     # setattr: registration hook
+        model.score_head.convDb.bias = torch.nn.Parameter(orig.clone())        # setattr: registration hook
         assert torch.equal(model(x)["score"], a)
-        model.score_head.convDb._parameters["bias"] = torch.nn.Parameter(bias.data + 1.0)   # behind torch's back
+        model.score_head.convDb._parameters["bias"] = torch.nn.Parameter(orig + 1.0)   # behind torch's back
         seen = False
         for _ in range(K._SIG_RECHECK + 1):
             seen = seen or not torch.equal(model(x)["score"], a)
