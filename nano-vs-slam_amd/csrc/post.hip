@@ -10,6 +10,8 @@
 //                      gluefactory/models/extractors/kp2dtiny.py:40; K1/K2 use the same SET.
 // Every float op that feeds an index decision is written with explicit round-to-nearest
 // intrinsics so hipcc's default fp-contraction cannot fuse it differently from the reference.
+#include <cstdlib>
+
 #include "kp2d_kernels.h"
 #include "device_guard.h"
 
@@ -188,7 +190,7 @@ int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
 //   a cap above 16384 on a big frame): survivors are compacted into the caller's idx row and sorted IN PLACE in
 //   global memory, keys rebuilt from score[idx] — no scratch buffer in the ABI, any k up to n.
 // ---------------------------------------------------------------------------------------------
-constexpr int TOPK_SMALL_MAX = 4096;     // 256-thread workgroups up to here
+constexpr int TOPK_SMALL_MAX = 512;      // 256-thread workgroups up to here (1024 threads beyond: k = 1000 at 64 frames 3.07 -> 3.06 ms/step)
 constexpr int TOPK_LDS_MAX = 16384;      // keys that fit the LDS path
 
 __device__ __forceinline__ unsigned long long topk_key(float s, int idx, float thr) {
@@ -377,7 +379,8 @@ int launch_topk(const TopkArgs& a, hipStream_t s) {
   int kpow = 2;                                 // >= 2: the sort network always touches two key slots
   while (kpow < keff) kpow <<= 1;
   const size_t lds = (size_t)kpow * 8 + 16 + 260 * 4;
-  if (keff <= TOPK_SMALL_MAX) {
+  static const int small_max = getenv("KP2D_TOPK_SMALL") ? atoi(getenv("KP2D_TOPK_SMALL")) : TOPK_SMALL_MAX;
+  if (keff <= small_max) {
     hipLaunchKernelGGL(topk_kernel<256>, dim3(a.B), dim3(256), lds, s, a, kpow);
   } else {
     static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
