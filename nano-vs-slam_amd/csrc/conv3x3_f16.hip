@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
     if (!KP2D_DBG_ON(8) && busy)
 #pragma unroll
     for (int slot = 0; slot < 9; slot += 2) {
+      // (timing emulation of Winograd F(2,3): bit 128 drops 5 of a chunk's 14 MFMA groups — results are wrong)
+      if (KP2D_DBG_ON(128) && slot >= 6) break;
       const int t = slot_tap(slot);
       const bool single = slot == 8;
       const bool dy = slot == 4;
@@ -340,6 +342,10 @@ static int launch_f(const ConvArgs& a0, hipStream_t s) {
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   const size_t lds_tile = (size_t)TH * TW * N * sizeof(float);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
+#ifdef KP2D_ABLATE
+  // Winograd F(2,3) emulation (KP2D_DBG bit 128): its transformed input image and its 12 weight slots need 35 KB more
+  if ((a.dbg & 128) && NH == 2) lds += 35 * 1024;
+#endif
   static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
   if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP, TH>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
