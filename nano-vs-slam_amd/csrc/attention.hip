@@ -358,6 +358,118 @@ __device__ __forceinline__ h16x4 lds_tr4(const _Float16* p) {
   return __builtin_bit_cast(h16x4, r);
 }
 
+// Online-softmax state of a wave's 32 queries
+struct AttAcc {
+  f32x16 o;        // O^T accumulator: rows 0..15 channels, row 16 the softmax denominator
+  f32x16 negm;     // -m in every register: the C operand of the score product
+  float m;         // running reference: the maximum score so far (0 before the first tile)
+  bool first;
+};
+
+// One 32-key tile: scores of the wave's 32 queries against LDS rows krow.. (this lane's K row, hi at +0 / lo at +16),
+// softmax update, P V through the transposed reads at vcur (see the kernels).  kglob = sequence index of the tile's
+// first key: only the last tile of a sequence has keys past T.
+__device__ __forceinline__ void att_tile(const _Float16* krow, const _Float16* vcur, const h16x8 qh, const h16x8 ql,
+                                         int kglob, int T, int h, AttAcc& st) {
+  const h16x8 kh = *reinterpret_cast<const h16x8*>(krow);
+  const h16x8 kl = *reinterpret_cast<const h16x8*>(krow + 16);
+  // The score accumulator starts at -m, the running reference of this query (kept as a 16-register vector that
+  // only changes when the reference moves): the products come out as s - m and the common tile — no key beats
+  // the reference — goes straight to exp2 with no per-score subtraction.  The kernel is bound by its VALU
+  // instruction count (11.6 per MFMA before this, profiles/r1_pmc_cfg4_summary.txt).
+  f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, st.negm, 0, 0, 0);
+  sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sc, 0, 0, 0);
+  sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sc, 0, 0, 0);
+  if (kglob + 32 > T) {                       // (uniform branch)
+    const int kbase = kglob + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (kbase + (r & 3) + 8 * (r >> 2) >= T) sc[r] = -INFINITY;
+  }
+  float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);      // v_max3_f32
+  mx = fmaxf(mx, sc[15]);
+  {
+    // the other 16 keys of this query sit in lane ^ 32: v_permlane32_swap exchanges the wave halves on the VALU
+    // (ds_bpermute was an LDS round trip plus an lgkmcnt(0) in the middle of every tile)
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  // first tile: the reference becomes the tile maximum whatever its sign (m and o start at 0); later it only rises
+  const float delta = st.first ? mx : fmaxf(mx, 0.f);
+  if (__any(delta != 0.f)) {                // some query of this wave moves its reference: shift and rescale
+    st.m += delta;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] -= delta; st.negm[r] = -st.m; }
+    if (!st.first) {
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) st.o[r] *= alpha;          // rows 0..15 (channels) and row 16 (denominator)
+    }
+  }
+  st.first = false;
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r]);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    h16x8 ph, pl;
+    const float (&pp)[8] = *reinterpret_cast<const float (*)[8]>(&p[8 * t]);
+    att_split8(pp, ph, pl);
+    const h16x4 vh0 = lds_tr4(vcur + (16 * t) * SVP), vl0 = lds_tr4(vcur + (16 * t) * SVP + 32);
+    const h16x4 vh1 = lds_tr4(vcur + (16 * t + 8) * SVP), vl1 = lds_tr4(vcur + (16 * t + 8) * SVP + 32);
+    const h16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+    const h16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+    st.o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, st.o, 0, 0, 0);
+    st.o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, st.o, 0, 0, 0);
+    st.o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, st.o, 0, 0, 0);
+  }
+}
+
+// Q^T operand of a query: lane (query i, h) holds channels 8h..8h+7, pre-multiplied by scale * log2(e) so that the
+// softmax runs on exp2 directly
+__device__ __forceinline__ void att_load_q(const AttnArgs& a, const float* qp, bool ok, int h, int d, h16x8& qh, h16x8& ql) {
+  const float f = a.scale * 1.44269504088896340736f;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = (ok && 8 * h + j < d) ? qp[8 * h + j] * f : 0.f;
+  att_split8(x, qh, ql);
+}
+
+// one staged granule: 4 channels of a key's K and V rows, split and written to the LDS images
+__device__ __forceinline__ void att_commit(_Float16* Ks, _Float16* Vs, int key, int q4, const float4 kk, const float4 vv) {
+  h16x2 h0, h1, l0, l1;
+  att_split2(kk.x, kk.y, h0, l0);
+  att_split2(kk.z, kk.w, h1, l1);
+  *reinterpret_cast<h16x4*>(&Ks[key * SKP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<h16x4*>(&Ks[key * SKP + 16 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
+  att_split2(vv.x, vv.y, h0, l0);
+  att_split2(vv.z, vv.w, h1, l1);
+  *reinterpret_cast<h16x4*>(&Vs[key * SVP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<h16x4*>(&Vs[key * SVP + 32 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// normalise and store a wave's 32 output rows (o[8] of the h = 0 lanes is the denominator)
+__device__ __forceinline__ void att_store(const f32x16& o, float* op, int h, int d) {
+  float l = o[8];                 // row 16 of O^T lives in register 8 of the h = 0 lanes (row 20, zero, for h = 1)
+  l += __shfl_xor(l, 32);
+  if (!op) return;
+  const float inv = 1.f / l;
+  // accumulator register r < 8 of lane-half h: channel (r & 3) + 8 (r >> 2) + 4h
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c0 = 8 * g + 4 * h;
+    if (c0 + 3 < d) {
+      *reinterpret_cast<float4*>(op + c0) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (c0 + r < d) op[c0 + r] = o[4 * g + r] * inv;
+    }
+  }
+}
+
 template <int NTHR, int WPS>   // threads per workgroup (32 queries per wave), waves per SIMD asked of the compiler
 __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
@@ -398,25 +510,13 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
   const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
   const int qi = qblk * (NTHR / 2) + wave * 32 + i;
-  // Q^T operand: lane (query i, h) holds channels 8h..8h+7, pre-multiplied by scale * log2(e) so that the
-  // softmax runs on exp2 directly
   h16x8 qh, ql;
-  {
-    const float* qp = a.q + ((size_t)b * S + (qi < S ? qi : 0)) * qs + hd * d;
-    const float f = a.scale * 1.44269504088896340736f;
-    float x[8];
+  att_load_q(a, a.q + ((size_t)b * S + (qi < S ? qi : 0)) * qs + hd * d, qi < S, h, d, qh, ql);
+  AttAcc st;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (qi < S && 8 * h + j < d) ? qp[8 * h + j] * f : 0.f;
-    att_split8(x, qh, ql);
-  }
-  f32x16 o;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m = 0.f;          // running reference of the online softmax: the maximum score so far (0 before the first tile)
-  f32x16 negm;            // -m in every register: the C operand of the score product
-#pragma unroll
-  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-  bool first = true;
+  for (int r = 0; r < 16; ++r) { st.o[r] = 0.f; st.negm[r] = 0.f; }
+  st.m = 0.f;
+  st.first = true;
   // Rows 16..31 of the V^T operand are padding (head dim <= 16).  Row 16 is set to ones, so that row 16 of O^T
   // accumulates the softmax denominator sum_k (ph + pl) on the matrix cores; the other padding rows are zeros.
   // V^T operand of k-step t (keys 16 t .. 16 t + 15 of the tile), lane-half h, element j = key 16 t + 8 (j >> 2) + 4 h +
@@ -448,103 +548,123 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
         kk = *reinterpret_cast<const float4*>(p);
         vv = *reinterpret_cast<const float4*>(p + vd);
       }
-      h16x2 h0, h1, l0, l1;
-      att_split2(kk.x, kk.y, h0, l0);
-      att_split2(kk.z, kk.w, h1, l1);
-      *reinterpret_cast<h16x4*>(&Ks[key * SKP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
-      *reinterpret_cast<h16x4*>(&Ks[key * SKP + 16 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
-      att_split2(vv.x, vv.y, h0, l0);
-      att_split2(vv.z, vv.w, h1, l1);
-      *reinterpret_cast<h16x4*>(&Vs[key * SVP + 4 * q4]) = h16x4{h0[0], h0[1], h1[0], h1[1]};
-      *reinterpret_cast<h16x4*>(&Vs[key * SVP + 32 + 4 * q4]) = h16x4{l0[0], l0[1], l1[0], l1[1]};
+      att_commit(Ks, Vs, key, q4, kk, vv);
     }
     __syncthreads();
     const int ntile = min(SKT, T - kc + 31) >> 5;
     const _Float16* vcur = vph;
     for (int t32 = 0; t32 < (SKT >> 5); ++t32) {
       if (t32 >= ntile) break;
-      // S^T tile: rows = keys 32*t32 + i
-      const h16x8 kh = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 8 * h]);
-      const h16x8 kl = *reinterpret_cast<const h16x8*>(&Ks[(t32 * 32 + i) * SKP + 16 + 8 * h]);
-      // The score accumulator starts at -m, the running reference of this query (kept as a 16-register vector that
-      // only changes when the reference moves): the products come out as s - m and the common tile — no key beats
-      // the reference — goes straight to exp2 with no per-score subtraction.  The kernel is bound by its VALU
-      // instruction count (11.6 per MFMA before this, profiles/r1_pmc_cfg4_summary.txt).
-      f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, negm, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sc, 0, 0, 0);
-      const int kbase = kc + t32 * 32 + 4 * h;
-      if (kc + t32 * 32 + 32 > T) {             // only the last tile of the sequence has keys past T (uniform branch)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kbase + (r & 3) + 8 * (r >> 2) >= T) sc[r] = -INFINITY;
-      }
-      float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);      // v_max3_f32
-      mx = fmaxf(mx, sc[15]);
-      {
-        // the other 16 keys of this query sit in lane ^ 32: v_permlane32_swap exchanges the wave halves on the VALU
-        // (ds_bpermute was an LDS round trip plus an lgkmcnt(0) in the middle of every tile)
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      // first tile: the reference becomes the tile maximum whatever its sign (m and o start at 0); later it only rises
-      const float delta = first ? mx : fmaxf(mx, 0.f);
-      if (__any(delta != 0.f)) {                // some query of this wave moves its reference: shift and rescale
-        m += delta;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] -= delta; negm[r] = -m; }
-        if (!first) {
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-          for (int r = 0; r < 9; ++r) o[r] *= alpha;          // rows 0..15 (channels) and row 16 (denominator)
-        }
-      }
-      first = false;
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r]);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        h16x8 ph, pl;
-        const float (&pp)[8] = *reinterpret_cast<const float (*)[8]>(&p[8 * t]);
-        att_split8(pp, ph, pl);
-        const h16x4 vh0 = lds_tr4(vcur + (16 * t) * SVP), vl0 = lds_tr4(vcur + (16 * t) * SVP + 32);
-        const h16x4 vh1 = lds_tr4(vcur + (16 * t + 8) * SVP), vl1 = lds_tr4(vcur + (16 * t + 8) * SVP + 32);
-        const h16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-        const h16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
-      }
+      att_tile(&Ks[(t32 * 32 + i) * SKP + 8 * h], vcur, qh, ql, kc + t32 * 32, T, h, st);
       vcur += 32 * SVP;       // next 32-key tile
     }
   }
-  float l = o[8];                 // row 16 of O^T lives in register 8 of the h = 0 lanes (row 20, zero, for h = 1)
-  l += __shfl_xor(l, 32);
-  if (qi < S) {
-    const float inv = 1.f / l;
-    float* op = a.out + ((size_t)b * S + qi) * os + hd * d;
-    // accumulator register r < 8 of lane-half h: channel (r & 3) + 8 (r >> 2) + 4h
+  att_store(st.o, qi < S ? a.out + ((size_t)b * S + qi) * os + hd * d : nullptr, h, d);
+}
+
+// Short sequences (the LightGlue matcher: one image pair is 2 sequences x 4 heads x 1024 keypoints).  The kernel
+// above gives a wave 32 queries and ALL keys: at one pair that is 64 workgroups, each wave a serial chain of 32 key
+// tiles and 8 barrier-fenced staging rounds with nothing else resident to hide them (23.7 us per launch, 40 % of the
+// matcher, profiles/r3_lightglue_kernels.txt).  Here the four waves of a workgroup share 32 queries and split the KEYS:
+// wave w owns keys [w Tw, (w+1) Tw), stages them itself 32 at a time into its own quarter of the LDS images (no
+// workgroup barrier in the loop: LDS operations of one wave execute in order; the next round's rows are fetched while
+// the current tile is multiplied), and the four partial (m, l, O) meet once in LDS at the end.  Grid = 8x the
+// workgroups, chain = T / 128 tiles.
+__global__ __launch_bounds__(256, 4) void attention_ksplit_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[SKT * SKP];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[SKT * SVP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
+  const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
+  const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
+  const int qi = blockIdx.x * 32 + i;
+  h16x8 qh, ql;
+  att_load_q(a, a.q + ((size_t)b * S + (qi < S ? qi : 0)) * qs + hd * d, qi < S, h, d, qh, ql);
+  AttAcc st;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int c0 = 8 * g + 4 * h;
-      if (c0 + 3 < d) {
-        *reinterpret_cast<float4*>(op + c0) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-      } else {
+  for (int r = 0; r < 16; ++r) { st.o[r] = 0.f; st.negm[r] = 0.f; }
+  st.m = 0.f;
+  st.first = true;
+  _Float16* const Kw = Ks + wave * 32 * SKP;             // this wave's 32 rows of the images
+  _Float16* const Vw = Vs + wave * 32 * SVP;
+  for (int e = lane; e < 32 * 4; e += 64) {              // the constant columns of the V rows (see the kernel above)
+    const int row = e >> 2, pt = e & 3;
+    h16x8 c = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pt == 0) c[0] = (_Float16)1.f;
+    *reinterpret_cast<h16x8*>(&Vw[row * SVP + 16 + 32 * (pt >> 1) + 8 * (pt & 1)]) = c;
+  }
+  const _Float16* const vph = &Vw[(4 * h + ((lane & 15) >> 2)) * SVP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
+  const int Tw = ((T + 127) >> 7) << 5;                  // keys per wave, a multiple of the 32-key tile
+  const int k0 = wave * Tw, k1 = min(T, k0 + Tw);
+  // granule (key, 4 channels) of a round: lane -> key lane / 4 (+ 16), channels 4 (lane % 4)
+  const int gkey = lane >> 2, gq = lane & 3;
+  float4 kk[2], vv[2];
+  auto fetch = [&](int kc) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r < d) op[c0 + r] = o[4 * g + r] * inv;
+    for (int u = 0; u < 2; ++u) {
+      kk[u] = make_float4(0.f, 0.f, 0.f, 0.f); vv[u] = kk[u];
+      const int key = kc + gkey + 16 * u;
+      if (key < k1 && 4 * gq < d) {
+        const float* p = kvb + (size_t)key * kvs + 4 * gq;
+        kk[u] = *reinterpret_cast<const float4*>(p);
+        vv[u] = *reinterpret_cast<const float4*>(p + vd);
       }
     }
+  };
+  if (k0 < k1) fetch(k0);
+  for (int kc = k0; kc < k1; kc += 32) {
+    att_commit(Kw, Vw, gkey, gq, kk[0], vv[0]);
+    att_commit(Kw, Vw, gkey + 16, gq, kk[1], vv[1]);
+    if (kc + 32 < k1) fetch(kc + 32);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (ordering only: one wave, in-order LDS)
+    att_tile(&Kw[i * SKP + 8 * h], vph, qh, ql, kc, T, h, st);      // (wave ranges are whole tiles: only the sequence's last tile is ragged)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  // merge: wave 0 adds the other waves' partial sums, rescaled to the common reference
+  const float mw = k0 < k1 ? st.m : -INFINITY;            // (a wave without keys carries no weight)
+  // (a wave's partial — m and O rows 0..8 of every lane, pitch 11 floats — goes where its V rows were)
+  auto part = [&](int w) { return reinterpret_cast<float*>(Vs + w * 32 * SVP) + lane * 11; };
+  if (wave) {
+    float* pw = part(wave);
+    pw[0] = mw;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) pw[1 + r] = st.o[r];
+  }
+  __syncthreads();
+  if (wave) return;
+  float mm = mw;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) mm = fmaxf(mm, part(w)[0]);
+  {
+    const float al = __builtin_amdgcn_exp2f(mw - mm);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) st.o[r] *= al;
+  }
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float* pw = part(w);
+    const float al = __builtin_amdgcn_exp2f(pw[0] - mm);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) st.o[r] = fmaf(pw[1 + r], al, st.o[r]);
+  }
+  att_store(st.o, qi < S ? a.out + ((size_t)b * S + qi) * os + hd * d : nullptr, h, d);
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t s) {
   const int d = a.C / a.heads;
   if (a.C % a.heads || d > 64 || (d & 3) || (a.C & 3)) return -1402;
   if (a.prec == 1 && d <= 16) {
+    // short sequences that leave most of the chip idle in the query-tiled kernel: split the keys over the waves
+    static const long ks_max = getenv("KP2D_ATT_KSPLIT") ? atol(getenv("KP2D_ATT_KSPLIT")) : 256;
+    if ((long)((a.S + 127) / 128) * a.heads * a.B < ks_max && a.T >= 128) {
+      hipLaunchKernelGGL(attention_ksplit_kernel, dim3((a.S + 31) / 32, a.heads, a.B), dim3(256), 0, s, a);
+      return (int)hipGetLastError();
+    }
     // 256 queries per workgroup halve the K / V staging per query (18 % of the kernel at 128); short sequences
     // keep 128 so that the grid still covers the chip
     static const int big = getenv("KP2D_ATT_Q") ? atoi(getenv("KP2D_ATT_Q")) : 256;

@@ -183,8 +183,9 @@ struct LgAssignArgs {
   const float* fz;                          // [B*M + B*N][fs]: final_proj(x) / D^0.25 in [0,D), matchability logit at D
   int fs, D, B, M, N;
   float* scores;                            // [B][M+1][N+1] log assignment (out)
-  float* rlse; float* clse; float* max0;    // scratch [B*M], [B*N], [B*M]
-  int* m0; int* m1;                         // scratch row / column argmax
+  // scratch, per 64 x 64 tile of the inner block: [B][ceil(N/64)][M] for rows, [B][ceil(M/64)][N] for columns
+  float* rp_m; float* rp_s; float* cp_m; float* cp_s;      // log-sum-exp partials of sim (maximum, sum of exp)
+  float* rmax; int* rarg; float* cmax; int* carg;          // max / argmax partials of the final scores
   float th;                                 // filter_threshold
   int64_t* matches0; int64_t* matches1; float* mscores0; float* mscores1;
 };

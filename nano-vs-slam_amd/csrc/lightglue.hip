@@ -8,16 +8,18 @@
 //  lg_linear_kernel     Y = X W^T + b with fused epilogues: rotary on the q|k columns (:158-159, :253-257),
 //                       LayerNorm + GELU (ffn.1, ffn.2), residual add (x + ffn(...), :261)
 //  (attention)          attention.hip: softmax(q k^T / sqrt(d)) v, streaming, split-fp16 matrix cores (:208-224, :312-321)
-//  lg_sim_kernel        sim = f0 f1^T (:391)
-//  lg_rowlse / lg_col   row / column log-sum-exp of sim, column argmax of the final scores
-//  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + row max/argmax (filter_matches :403-404)
+//  lg_sim_kernel        sim = f0 f1^T (:391) + per-tile row / column log-sum-exp partials
+//  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + per-tile row / column max, argmax (filter_matches :403-404)
 //  lg_filter_kernel     mutual check, threshold, match scores (:405-416)
+#include <cstdlib>
 #include "kp2d_kernels.h"
 #include "device_guard.h"
 
 namespace kp2d {
 
-// one workgroup per (image set, batch item): keypoints [n][2] -> cs[row][hd] = (cos f0..f_{hd/2-1} | sin ...)
+// keypoints [n][2] -> cs[row][hd] = (cos f0..f_{hd/2-1} | sin ...).  Grid (batch item, image set, slice): every
+// workgroup finds the keypoint extent itself (n <= a few thousand values, L2-resident) and writes one slice of the
+// table — one workgroup per (item, set) was a 12-us serial chain of sincos at 1024 keypoints
 __global__ __launch_bounds__(256) void lg_posenc_kernel(const LgPosArgs a) {
   __shared__ float red[4][4];
   const int set = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void lg_posenc_kernel(const LgPosArgs a) {
   const float scale = fmaxf(sx, sy) / 2.f;
   const int hf = a.hd >> 1;
   float* cs = a.cs + ((size_t)(set ? a.B * a.M : 0) + (size_t)b * n) * a.hd;
-  for (int e = tid; e < n * hf; e += 256) {
+  for (int e = blockIdx.z * 256 + tid; e < n * hf; e += 256 * gridDim.z) {
     const int i = e / hf, f = e - i * hf;
     const float x = (k[2 * i] - sx / 2.f) / scale, y = (k[2 * i + 1] - sy / 2.f) / scale;
     const float pr = a.wr[2 * f] * x + a.wr[2 * f + 1] * y;
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void lg_posenc_kernel(const LgPosArgs a) {
 
 int launch_lg_posenc(const LgPosArgs& a, hipStream_t s) {
   if (a.hd < 2 || (a.hd & 1)) return -1800;
-  hipLaunchKernelGGL(lg_posenc_kernel, dim3(a.B, 2), dim3(256), 0, s, a);
+  const int work = ((a.M > a.N ? a.M : a.N) * (a.hd >> 1) + 255) / 256;
+  hipLaunchKernelGGL(lg_posenc_kernel, dim3(a.B, 2, work < 16 ? work : 16), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -203,14 +206,24 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int RT> __device__ __forceinline__ void lg_rows(const float* p, float (&x)[RT]) {      // RT adjacent LDS floats
+  if constexpr (RT == 4) { const float4 v = *reinterpret_cast<const float4*>(p); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+  else if constexpr (RT == 2) { const float2 v = *reinterpret_cast<const float2*>(p); x[0] = v.x; x[1] = v.y; }
+  else x[0] = *p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused block tail for D = 32: message = out_proj(ctx); h = GELU(LayerNorm(W1 [x | message] + b1)); x += W2 h + b2.
-// All three products are row-local, so one workgroup carries its 64 rows through them with the intermediate tiles
+// All three products are row-local, so one workgroup carries its 16 RT rows through them with the intermediate tiles
 // (transposed, [k][row]) in LDS: 3 launches and 2 HBM round trips of the message / hidden tensors less per block.
-// Same thread mapping as lg_linear_kernel (thread = 4 rows x column pairs {2cg + 32j, +1}).
+// Thread mapping of lg_linear_kernel (thread = RT rows x column pairs {2cg + 32j, +1}); a row's arithmetic does not
+// depend on RT.  One image pair is 2048 rows: at 64 rows per workgroup (RT = 4) that was 32 workgroups walking the
+// 192 k-steps of the four products on 32 of the 256 CUs, 20 us per launch (RT = 1: 128 workgroups, 0.404 -> 0.348 ms per
+// forward, profiles/r3_lightglue_kernels.txt).
 // ---------------------------------------------------------------------------------------------
+template <int RT>   // rows per thread: a workgroup carries 16 * RT rows
 __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
-  constexpr int D = 32, D2 = 64, R = LG_ROWS;
+  constexpr int D = 32, D2 = 64, R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wo = sm;                  // [D][D]
   float* w1 = wo + D * D;          // [D2][D2]
@@ -236,37 +249,37 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
   __syncthreads();
   // ---- stage 1: message[64 x 32] = ctx Wo^T + bo -> xt rows D..2D ----
   {
-    float acc[4][2] = {};
+    float acc[RT][2] = {};
     for (int k = 0; k < D; ++k) {
-      const float4 xv = *reinterpret_cast<const float4*>(&ct[k * R + 4 * rg]);
+      float xr[RT];
+      lg_rows<RT>(&ct[k * R + RT * rg], xr);
       const float2 wv = *reinterpret_cast<const float2*>(&wo[k * D + 2 * cg]);
-      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
+      for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
     }
     const float b0 = a.bo[2 * cg], b1 = a.bo[2 * cg + 1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      xt[(D + 2 * cg) * R + 4 * rg + r] = acc[r][0] + b0;
-      xt[(D + 2 * cg + 1) * R + 4 * rg + r] = acc[r][1] + b1;
+    for (int r = 0; r < RT; ++r) {
+      xt[(D + 2 * cg) * R + RT * rg + r] = acc[r][0] + b0;
+      xt[(D + 2 * cg + 1) * R + RT * rg + r] = acc[r][1] + b1;
     }
   }
   __syncthreads();
   // ---- stage 2: h[64 x 64] = GELU(LayerNorm([x | message] W1^T + b1)) ----
-  float h[4][4];
+  float h[RT][4];
   {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) h[r][c] = 0.f;
     for (int k = 0; k < D2; ++k) {
-      const float4 xv = *reinterpret_cast<const float4*>(&xt[k * R + 4 * rg]);
-      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+      float xr[RT];
+      lg_rows<RT>(&xt[k * R + RT * rg], xr);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float2 wv = *reinterpret_cast<const float2*>(&w1[k * D2 + 2 * cg + 32 * j]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r][2 * j] = fmaf(xr[r], wv.x, h[r][2 * j]); h[r][2 * j + 1] = fmaf(xr[r], wv.y, h[r][2 * j + 1]); }
+        for (int r = 0; r < RT; ++r) { h[r][2 * j] = fmaf(xr[r], wv.x, h[r][2 * j]); h[r][2 * j + 1] = fmaf(xr[r], wv.y, h[r][2 * j + 1]); }
       }
     }
     float bb[4], gg[4], be[4];
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
       bb[c] = a.b1[col]; gg[c] = a.ln_g[col]; be[c] = a.ln_b[col];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RT; ++r) {
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) { h[r][c] += bb[c]; s += h[r][c]; }
@@ -296,27 +309,27 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
   }
   __syncthreads();                 // every thread is done reading (x | message)^T and W1
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + 4 * rg + r] = h[r][c];
+    for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + RT * rg + r] = h[r][c];
   // the next projection's weights take W1's place (D x nn <= 32 x 96 floats)
   if (a.nn)
     for (int e = tid; e < (D * a.nn) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.wn)[e];
   __syncthreads();
   // ---- stage 3: x += h W2^T + b2 ----
   {
-    float acc[4][2] = {};
+    float acc[RT][2] = {};
     for (int k = 0; k < D2; ++k) {
-      const float4 xv = *reinterpret_cast<const float4*>(&xt[k * R + 4 * rg]);
+      float xr[RT];
+      lg_rows<RT>(&xt[k * R + RT * rg], xr);
       const float2 wv = *reinterpret_cast<const float2*>(&w2[k * D + 2 * cg]);
-      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
+      for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
     }
     const float b0 = a.b2[2 * cg], b1 = a.b2[2 * cg + 1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * rg + r;
+    for (int r = 0; r < RT; ++r) {
+      const int row = row0 + RT * rg + r;
       float2 nx = make_float2(0.f, 0.f);
       if (row < a.rows) {
         float2* xp = reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg);
@@ -325,8 +338,8 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
         *xp = nx;
       }
       if (a.nn) {                    // updated x, transposed, for stage 4 (ctx^T is no longer needed)
-        ct[(2 * cg) * R + 4 * rg + r] = nx.x;
-        ct[(2 * cg + 1) * R + 4 * rg + r] = nx.y;
+        ct[(2 * cg) * R + RT * rg + r] = nx.x;
+        ct[(2 * cg + 1) * R + RT * rg + r] = nx.y;
       }
     }
   }
@@ -335,20 +348,20 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
   // ---- stage 4: the next projection of the updated rows (same arithmetic and order as lg_linear_kernel) ----
   {
     const int nn = a.nn, nj = nn >> 5;
-    float acc[4][6];
+    float acc[RT][6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[r][c] = 0.f;
     for (int k = 0; k < D; ++k) {
-      const float4 xv = *reinterpret_cast<const float4*>(&ct[k * R + 4 * rg]);
-      const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+      float xr[RT];
+      lg_rows<RT>(&ct[k * R + RT * rg], xr);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         if (j < nj) {
           const float2 wv = *reinterpret_cast<const float2*>(&w1[k * nn + 2 * cg + 32 * j]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < RT; ++r) {
             acc[r][2 * j] = fmaf(xr[r], wv.x, acc[r][2 * j]);
             acc[r][2 * j + 1] = fmaf(xr[r], wv.y, acc[r][2 * j + 1]);
           }
@@ -363,8 +376,8 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
         const bool rot = a.cs && c < a.rot_cols;
         const int hf = a.hd >> 1, f = rot ? (c % a.hd) >> 1 : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = row0 + 4 * rg + r;
+        for (int r = 0; r < RT; ++r) {
+          const int row = row0 + RT * rg + r;
           if (row >= a.rows || c >= a.nvalid) continue;
           float y0 = acc[r][2 * j] + b0, y1 = acc[r][2 * j + 1] + b1;
           if (rot) {
@@ -385,15 +398,38 @@ int launch_lg_tail(const LgTailArgs& a, hipStream_t s) {
   if (a.D != 32) return -1804;
   if (a.nn && (a.nn != 64 && a.nn != 96)) return -1805;
   if (a.nn && (!a.wn || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.cs && ((a.hd & 1) || (a.rot_cols & 1))))) return -1805;
-  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + 32 * LG_ROWS + 64 * LG_ROWS) * sizeof(float);
-  hipLaunchKernelGGL(lg_tail_kernel, dim3((a.rows + LG_ROWS - 1) / LG_ROWS), dim3(256), lds, s, a);
+  static const int forced = getenv("KP2D_LG_TAIL_RT") ? atoi(getenv("KP2D_LG_TAIL_RT")) : 0;
+  const int rt = forced ? forced : a.rows >= 64 * 256 ? 4 : a.rows >= 32 * 256 ? 2 : 1;      // (8 pairs x 2048 rows: 0.547 / 0.595 / 0.569 ms per forward at RT = 4 / 2 / 1)
+  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + (32 + 64) * 16 * rt) * sizeof(float);
+  const dim3 grid((a.rows + 16 * rt - 1) / (16 * rt));
+  switch (rt) {
+    case 4: hipLaunchKernelGGL(lg_tail_kernel<4>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(lg_tail_kernel<2>, grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(lg_tail_kernel<1>, grid, dim3(256), lds, s, a); break;
+    default: return -1806;
+  }
   return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Assignment.  scores is the reference's [B][M+1][N+1] log-assignment tensor; its inner block first holds sim.
+// Three launches over 64 x 64 tiles of the inner block (the first version walked whole rows and whole columns in
+// six: its two column walks alone were 33 + 25 us of a 96-us stage at one pair, profiles/r3_lightglue_kernels.txt):
+//   lg_sim_kernel       sim tile -> scores, plus the tile's partial log-sum-exp of every row and column
+//   lg_finalize_kernel  merges the partials of its rows / columns, writes the final tile, the border row / column,
+//                       and the tile's partial max / argmax of every row and column
+//   lg_filter_kernel    merges the argmax partials it needs and applies filter_matches
+// A partial is indexed [b][tile][row or column]; merges run in increasing tile order, so ties resolve to the lowest
+// index as torch.max does and the result does not depend on the grid.
 // ---------------------------------------------------------------------------------------------
-// sim tile 64 x 64 per workgroup; thread (ty = tid/16, tx = tid%16) owns a 4 x 4 block
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  const float mm = fmaxf(m, m2);
+  if (mm == -INFINITY) { m = mm; s = 0.f; return; }
+  s = s * expf(m - mm) + s2 * expf(m2 - mm);
+  m = mm;
+}
+
+// thread (ty = tid/16, tx = tid%16) owns rows i0 + 4 ty + r, columns j0 + 4 tx + c of the tile
 __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   __shared__ __attribute__((aligned(16))) float at[64 * 64], bt[64 * 64];   // [k][row]
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
@@ -424,131 +460,217 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
     for (int c = 0; c < 4; ++c) {
       const int i = i0 + 4 * ty + r, j = j0 + 4 * tx + c;
       if (i < M && j < N) sc[(size_t)i * (N + 1) + j] = acc[r][c];
+      else acc[r][c] = -INFINITY;            // outside the inner block: no weight in the sums below
     }
-}
-
-__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
-  const float mm = fmaxf(m, m2);
-  if (mm == -INFINITY) { m = mm; s = 0.f; return; }
-  s = s * expf(m - mm) + s2 * expf(m2 - mm);
-  m = mm;
-}
-
-// one wave per row i < M: log-sum-exp over the N columns of sim
-__global__ __launch_bounds__(256) void lg_rowlse_kernel(const LgAssignArgs a) {
-  const int lane = threadIdx.x & 63, M = a.M, N = a.N;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)a.B * M) return;
-  const int b = (int)(row / M), i = (int)(row - (long)b * M);
-  const float* sc = a.scores + (size_t)b * (M + 1) * (N + 1) + (size_t)i * (N + 1);
-  float m = -INFINITY, s = 0.f;
-  for (int j = lane; j < N; j += 64) lse_merge(m, s, sc[j], 1.f);
-  for (int o = 32; o > 0; o >>= 1) lse_merge(m, s, __shfl_xor(m, o), __shfl_xor(s, o));
-  if (lane == 0) a.rlse[row] = m + logf(s);
-}
-
-// 64 columns x 4 row slices per workgroup.  MODE 0: column log-sum-exp of sim -> clse.
-// MODE 1: column max / argmax (lowest row on ties) of the final scores -> m1.
-template <int MODE>
-__global__ __launch_bounds__(256) void lg_col_kernel(const LgAssignArgs a) {
-  __shared__ float sm_m[4][64], sm_s[4][64];
-  __shared__ int sm_i[4][64];
-  const int b = blockIdx.y, M = a.M, N = a.N;
-  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
-  const float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
-  float m = -INFINITY, s = 0.f;
-  int arg = 0;
-  if (j < N) {
-    // four rows in flight per thread: the column walk is a chain of dependent, latency-bound loads otherwise
-    int i = sl;
-    for (; i + 12 < M; i += 16) {
-      const float v0 = sc[(size_t)i * (N + 1) + j], v1 = sc[(size_t)(i + 4) * (N + 1) + j];
-      const float v2 = sc[(size_t)(i + 8) * (N + 1) + j], v3 = sc[(size_t)(i + 12) * (N + 1) + j];
-      if (MODE == 0) {
-        const float mm = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), m);
-        s = s * expf(m - mm) + expf(v0 - mm) + expf(v1 - mm) + expf(v2 - mm) + expf(v3 - mm);
-        m = mm;
-      } else {
-        if (v0 > m) { m = v0; arg = i; }
-        if (v1 > m) { m = v1; arg = i + 4; }
-        if (v2 > m) { m = v2; arg = i + 8; }
-        if (v3 > m) { m = v3; arg = i + 12; }
-      }
+  // rows: the 16 threads of a row group are 16 adjacent lanes
+  const int TN = gridDim.x, TM = gridDim.y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m = fmaxf(fmaxf(acc[r][0], acc[r][1]), fmaxf(acc[r][2], acc[r][3]));
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s += expf(acc[r][c] - m);
     }
-    for (; i < M; i += 4) {
-      const float v = sc[(size_t)i * (N + 1) + j];
-      if (MODE == 0) lse_merge(m, s, v, 1.f);
-      else if (v > m) { m = v; arg = i; }
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const int i = i0 + 4 * ty + r;
+    if (tx == 0 && i < M) {
+      const size_t e = ((size_t)b * TN + blockIdx.x) * M + i;
+      a.rp_m[e] = m; a.rp_s[e] = s;
     }
   }
-  sm_m[sl][c] = m; sm_s[sl][c] = s; sm_i[sl][c] = arg;
+  // columns: the 16 row groups of a column are lane bits 4-5 of the four waves
+  __syncthreads();                           // at / bt are free: reuse their first words for the cross-wave step
+  float* cm = at;                            // [4 waves][64 columns]
+  float* cs = at + 256;
+  const int wave = tid >> 6, q = (tid >> 4) & 3;
+  float m4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float m = fmaxf(fmaxf(acc[0][c], acc[1][c]), fmaxf(acc[2][c], acc[3][c]));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (q == 0) cm[wave * 64 + 4 * tx + c] = m;
+  }
   __syncthreads();
-  if (sl == 0 && j < N) {
-    for (int t = 1; t < 4; ++t) {
-      if (MODE == 0) lse_merge(m, s, sm_m[t][c], sm_s[t][c]);
-      else if (sm_m[t][c] > m || (sm_m[t][c] == m && sm_i[t][c] < arg)) { m = sm_m[t][c]; arg = sm_i[t][c]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 4 * tx + c;
+    const float m = fmaxf(fmaxf(cm[col], cm[64 + col]), fmaxf(cm[128 + col], cm[192 + col]));
+    m4[c] = m;
+    float s = 0.f;
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += expf(acc[r][c] - m);
     }
-    if (MODE == 0) a.clse[(size_t)b * N + j] = m + logf(s);
-    else a.m1[(size_t)b * N + j] = arg;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (q == 0) cs[wave * 64 + col] = s;
+  }
+  __syncthreads();
+  if (wave == 0 && q == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 4 * tx + c, j = j0 + col;
+      if (j < N) {
+        const size_t e = ((size_t)b * TM + blockIdx.y) * N + j;
+        a.cp_m[e] = m4[c];
+        a.cp_s[e] = ((cs[col] + cs[64 + col]) + cs[128 + col]) + cs[192 + col];
+      }
+    }
   }
 }
 
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 
-// one wave per row i <= M of scores: inner block <- log_softmax rows + log_softmax cols + certainties, last column /
-// last row <- logsigmoid(-z); also the row max / argmax of the inner block (lowest column on ties)
+// one 64 x 64 tile of scores: inner block <- log_softmax rows + log_softmax cols + certainties
+// (sigmoid_log_double_softmax, :363-376); the tiles of the first tile column / row also write the border column / row
+// (logsigmoid(-z)); plus the tile's row / column max and argmax of the final values for filter_matches (:403-404)
 __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) {
-  const int lane = threadIdx.x & 63, M = a.M, N = a.N;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)a.B * (M + 1)) return;
-  const int b = (int)(row / (M + 1)), i = (int)(row - (long)b * (M + 1));
-  float* sc = a.scores + (size_t)b * (M + 1) * (N + 1) + (size_t)i * (N + 1);
-  const float* z1 = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs + a.D;     // matchability column of image 1
-  if (i == M) {
-    for (int j = lane; j < N; j += 64) sc[j] = log_sigmoid(-z1[(size_t)j * a.fs]);
-    if (lane == 0) sc[N] = 0.f;
-    return;
+  __shared__ float s_base[64], s_col[64], s_ls1[64];
+  __shared__ float s_cm[4][64];
+  __shared__ int s_ci[4][64];
+  const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, M = a.M, N = a.N, TN = gridDim.x, TM = gridDim.y;
+  float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
+  const float* z0p = a.fz + (size_t)b * M * a.fs + a.D;                          // matchability logits of image 0
+  const float* z1p = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs + a.D;      // ... of image 1
+  if (tid < 64) {
+    const int i = i0 + tid;
+    float base = 0.f;
+    if (i < M) {
+      float m = -INFINITY, s = 0.f;
+      for (int t = 0; t < TN; ++t) {
+        const size_t e = ((size_t)b * TN + t) * M + i;
+        lse_merge(m, s, a.rp_m[e], a.rp_s[e]);
+      }
+      const float z0 = z0p[(size_t)i * a.fs];
+      base = log_sigmoid(z0) - (m + logf(s));
+      if (blockIdx.x == 0) sc[(size_t)i * (N + 1) + N] = log_sigmoid(-z0);
+    }
+    s_base[tid] = base;
+  } else if (tid < 128) {
+    const int c = tid - 64, j = j0 + c;
+    float cl = 0.f, ls1 = 0.f;
+    if (j < N) {
+      float m = -INFINITY, s = 0.f;
+      for (int t = 0; t < TM; ++t) {
+        const size_t e = ((size_t)b * TM + t) * N + j;
+        lse_merge(m, s, a.cp_m[e], a.cp_s[e]);
+      }
+      cl = m + logf(s);
+      const float z1 = z1p[(size_t)j * a.fs];
+      ls1 = log_sigmoid(z1);
+      if (blockIdx.y == 0) sc[(size_t)M * (N + 1) + j] = log_sigmoid(-z1);
+    }
+    s_col[c] = cl; s_ls1[c] = ls1;
+  } else if (tid == 128 && blockIdx.x == 0 && blockIdx.y == 0) {
+    sc[(size_t)M * (N + 1) + N] = 0.f;
   }
-  const float z0 = a.fz[((size_t)b * M + i) * a.fs + a.D];
-  const float base = log_sigmoid(z0) - a.rlse[(size_t)b * M + i];
-  const float* cl = a.clse + (size_t)b * N;
-  float mx = -INFINITY;
-  int arg = 0;
-  for (int j = lane; j < N; j += 64) {
-    const float v = 2.f * sc[j] + base - cl[j] + log_sigmoid(z1[(size_t)j * a.fs]);
-    sc[j] = v;
-    if (v > mx) { mx = v; arg = j; }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float v[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 4 * ty + r;
+    const float base = s_base[4 * ty + r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + 4 * tx + c;
+      float x = -INFINITY;
+      if (i < M && j < N) {
+        float* p = sc + (size_t)i * (N + 1) + j;
+        x = 2.f * *p + base - s_col[4 * tx + c] + s_ls1[4 * tx + c];
+        *p = x;
+      }
+      v[r][c] = x;
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const float m2 = __shfl_xor(mx, o);
-    const int a2 = __shfl_xor(arg, o);
-    if (m2 > mx || (m2 == mx && a2 < arg)) { mx = m2; arg = a2; }
+  // row max / argmax over the tile's columns (lowest column on ties)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float mx = v[r][0];
+    int arg = j0 + 4 * tx;
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+      if (v[r][c] > mx) { mx = v[r][c]; arg = j0 + 4 * tx + c; }
+    for (int o = 1; o < 16; o <<= 1) {
+      const float m2 = __shfl_xor(mx, o);
+      const int a2 = __shfl_xor(arg, o);
+      if (m2 > mx || (m2 == mx && a2 < arg)) { mx = m2; arg = a2; }
+    }
+    const int i = i0 + 4 * ty + r;
+    if (tx == 0 && i < M) {
+      const size_t e = ((size_t)b * TN + blockIdx.x) * M + i;
+      a.rmax[e] = mx; a.rarg[e] = arg;
+    }
   }
-  if (lane == 0) {
-    sc[N] = log_sigmoid(-z0);
-    a.max0[(size_t)b * M + i] = mx;
-    a.m0[(size_t)b * M + i] = arg;
+  // column max / argmax over the tile's rows (lowest row on ties)
+  const int wave = tid >> 6, q = (tid >> 4) & 3;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float mx = v[0][c];
+    int arg = i0 + 4 * ty;
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+      if (v[r][c] > mx) { mx = v[r][c]; arg = i0 + 4 * ty + r; }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float m2 = __shfl_xor(mx, o);
+      const int a2 = __shfl_xor(arg, o);
+      if (m2 > mx || (m2 == mx && a2 < arg)) { mx = m2; arg = a2; }
+    }
+    if (q == 0) { s_cm[wave][4 * tx + c] = mx; s_ci[wave][4 * tx + c] = arg; }
+  }
+  __syncthreads();
+  if (tid < 64 && j0 + tid < N) {
+    float mx = s_cm[0][tid];
+    int arg = s_ci[0][tid];
+    for (int w = 1; w < 4; ++w)
+      if (s_cm[w][tid] > mx) { mx = s_cm[w][tid]; arg = s_ci[w][tid]; }      // waves hold increasing rows: strict > keeps the lowest
+    const size_t e = ((size_t)b * TM + blockIdx.y) * N + j0 + tid;
+    a.cmax[e] = mx; a.carg[e] = arg;
   }
 }
 
 // filter_matches (:401-416): thread e < M handles row e, thread e >= M column e - M
 __global__ __launch_bounds__(256) void lg_filter_kernel(const LgAssignArgs a) {
   const int b = blockIdx.y, M = a.M, N = a.N;
+  const int TN = (N + 63) >> 6, TM = (M + 63) >> 6;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  const int* m0 = a.m0 + (size_t)b * M;
-  const int* m1 = a.m1 + (size_t)b * N;
-  const float* mx = a.max0 + (size_t)b * M;
+  auto row_best = [&](int i, float& mx) {
+    mx = -INFINITY;
+    int arg = 0;
+    for (int t = 0; t < TN; ++t) {
+      const size_t k = ((size_t)b * TN + t) * M + i;
+      const float v = a.rmax[k];
+      if (v > mx) { mx = v; arg = a.rarg[k]; }
+    }
+    return arg;
+  };
+  auto col_best = [&](int j) {
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int t = 0; t < TM; ++t) {
+      const size_t k = ((size_t)b * TM + t) * N + j;
+      const float v = a.cmax[k];
+      if (v > mx) { mx = v; arg = a.carg[k]; }
+    }
+    return arg;
+  };
   if (e < M) {
-    const int j = m0[e];
-    const bool mutual = m1[j] == e;
-    const float ms = mutual ? expf(mx[e]) : 0.f;
+    float mx;
+    const int j = row_best(e, mx);
+    const bool mutual = col_best(j) == e;
+    const float ms = mutual ? expf(mx) : 0.f;
     a.mscores0[(size_t)b * M + e] = ms;
     a.matches0[(size_t)b * M + e] = (mutual && ms > a.th) ? (int64_t)j : (int64_t)-1;
   } else if (e < M + N) {
-    const int j = e - M, i = m1[j];
-    const bool mutual1 = m0[i] == j;                 // then m1[m0[i]] == i as well: row i is mutual with column j
-    const float ms0 = mutual1 ? expf(mx[i]) : 0.f;
+    const int j = e - M, i = col_best(j);
+    float mx;
+    const bool mutual1 = row_best(i, mx) == j;       // then m1[m0[i]] == i as well: row i is mutual with column j
+    const float ms0 = mutual1 ? expf(mx) : 0.f;
     a.mscores1[(size_t)b * N + j] = ms0;
     a.matches1[(size_t)b * N + j] = (mutual1 && ms0 > a.th) ? (int64_t)i : (int64_t)-1;
   }
@@ -556,11 +678,9 @@ __global__ __launch_bounds__(256) void lg_filter_kernel(const LgAssignArgs a) {
 
 int launch_lg_assign(const LgAssignArgs& a, hipStream_t s) {
   if (a.D < 1 || a.D > 64 || a.M < 1 || a.N < 1) return -1803;
-  hipLaunchKernelGGL(lg_sim_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(lg_rowlse_kernel, dim3((int)(((long)a.B * a.M + 3) / 4)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(lg_col_kernel<0>, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(lg_finalize_kernel, dim3((int)(((long)a.B * (a.M + 1) + 3) / 4)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(lg_col_kernel<1>, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
+  const dim3 tiles((a.N + 63) / 64, (a.M + 63) / 64, a.B);
+  hipLaunchKernelGGL(lg_sim_kernel, tiles, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(lg_finalize_kernel, tiles, dim3(256), 0, s, a);
   hipLaunchKernelGGL(lg_filter_kernel, dim3((a.M + a.N + 255) / 256, a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }

@@ -169,7 +169,7 @@ int pack(kp2d_lg* m, std::vector<float>& blob) {
 }
 
 struct Ws {
-  size_t x, t3, ctx, msg, hb, cs, fz, rlse, clse, max0, m0, m1, total;
+  size_t x, t3, ctx, msg, hb, cs, fz, rp_m, rp_s, cp_m, cp_s, rmax, rarg, cmax, carg, total;
 };
 Ws layout(const kp2d_lg* m, int B, int M, int N) {
   const size_t R = (size_t)B * (M + N), d = m->cfg.descriptor_dim, hd = d / m->cfg.num_heads;
@@ -178,8 +178,9 @@ Ws layout(const kp2d_lg* m, int B, int M, int N) {
   auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4); return o; };
   w.x = take(R * d); w.t3 = take(R * 3 * d); w.ctx = take(R * d); w.msg = take(R * d); w.hb = take(R * 2 * d);
   w.cs = take(R * hd); w.fz = take(R * (d + 32));
-  w.rlse = take((size_t)B * M); w.clse = take((size_t)B * N); w.max0 = take((size_t)B * M);
-  w.m0 = take((size_t)B * M); w.m1 = take((size_t)B * N);
+  const size_t rp = (size_t)B * ((N + 63) / 64) * M, cp = (size_t)B * ((M + 63) / 64) * N;      // per-tile partials
+  w.rp_m = take(rp); w.rp_s = take(rp); w.cp_m = take(cp); w.cp_s = take(cp);
+  w.rmax = take(rp); w.rarg = take(rp); w.cmax = take(cp); w.carg = take(cp);
   w.total = off;
   return w;
 }
@@ -401,11 +402,16 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     if (!fused || m->cfg.n_layers == 0) LG_CHECK(launch_lg_linear(a, st), "log_assignment.final_proj");
     LgAssignArgs g{};
     g.fz = FZ; g.fs = d + 32; g.D = d; g.B = B; g.M = M; g.N = N; g.scores = log_assignment;
-    g.rlse = F(w.rlse); g.clse = F(w.clse); g.max0 = F(w.max0);
-    g.m0 = reinterpret_cast<int*>(base + w.m0); g.m1 = reinterpret_cast<int*>(base + w.m1);
+    g.rp_m = F(w.rp_m); g.rp_s = F(w.rp_s); g.cp_m = F(w.cp_m); g.cp_s = F(w.cp_s);
+    g.rmax = F(w.rmax); g.cmax = F(w.cmax);
+    g.rarg = reinterpret_cast<int*>(base + w.rarg); g.carg = reinterpret_cast<int*>(base + w.carg);
     g.th = filter_threshold;
     g.matches0 = matches0; g.matches1 = matches1; g.mscores0 = mscores0; g.mscores1 = mscores1;
     LG_CHECK(launch_lg_assign(g, st), "log_assignment");
+  }
+  if (ref_desc0 && ref_desc1 == ref_desc0 + (size_t)R0 * d) {      // one buffer behind both outputs: one copy
+    HIP_TRY(hipMemcpyAsync(ref_desc0, X, (size_t)R * d * 4, hipMemcpyDeviceToDevice, st));
+    return KP2D_OK;
   }
   if (ref_desc0) HIP_TRY(hipMemcpyAsync(ref_desc0, X, (size_t)R0 * d * 4, hipMemcpyDeviceToDevice, st));
   if (ref_desc1) HIP_TRY(hipMemcpyAsync(ref_desc1, X + (size_t)R0 * d, (size_t)B * N * d * 4, hipMemcpyDeviceToDevice, st));

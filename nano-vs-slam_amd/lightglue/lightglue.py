@@ -195,7 +195,8 @@ class LightGlue(nn.Module):
         m0 = torch.empty(b, m, dtype=torch.int64, device=dev)
         m1 = torch.empty(b, n, dtype=torch.int64, device=dev)
         ms0, ms1 = torch.empty(b, m, device=dev), torch.empty(b, n, device=dev)
-        ref0, ref1 = torch.empty(b, m, d, device=dev), torch.empty(b, n, d, device=dev)
+        ref = torch.empty(b * (m + n), d, device=dev)      # one buffer: the library copies both images' rows at once
+        ref0, ref1 = ref[:b * m].view(b, m, d), ref[b * m:].view(b, n, d)
         need = lib.kp2d_lg_workspace_bytes(h, b, m, n)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -204,11 +205,13 @@ class LightGlue(nn.Module):
                                        b, m, n, float(self.conf.filter_threshold), _ptr(scores), _ptr(m0), _ptr(m1),
                                        _ptr(ms0), _ptr(ms1), _ptr(ref0), _ptr(ref1), _ptr(self._ws), self._ws.numel(),
                                        C.c_void_p(stream)))
+        # (no pruning is built: every point survives all layers; one fill instead of two ones_like * n)
+        prune = torch.full((b * (m + n),), float(self.conf.n_layers), device=dev)
         return {
             "matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1,
             "ref_descriptors0": ref0[:, None], "ref_descriptors1": ref1[:, None],
             "log_assignment": scores,
-            "prune0": torch.ones_like(ms0) * self.conf.n_layers, "prune1": torch.ones_like(ms1) * self.conf.n_layers,
+            "prune0": prune[:b * m].view(b, m), "prune1": prune[b * m:].view(b, n),
         }
 
 
