@@ -12,6 +12,7 @@
 //  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + per-tile row / column max, argmax (filter_matches :403-404)
 //  lg_filter_kernel     mutual check, threshold, match scores (:405-416)
 #include <cstdlib>
+#include <type_traits>
 #include "kp2d_kernels.h"
 #include "device_guard.h"
 
@@ -206,6 +207,7 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+constexpr int LG_TAIL_VEC = 352;      // floats of bias / LayerNorm vectors staged by lg_tail_kernel
 template <int RT> __device__ __forceinline__ void lg_rows(const float* p, float (&x)[RT]) {      // RT adjacent LDS floats
   if constexpr (RT == 4) { const float4 v = *reinterpret_cast<const float4*>(p); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
   else if constexpr (RT == 2) { const float2 v = *reinterpret_cast<const float2*>(p); x[0] = v.x; x[1] = v.y; }
@@ -228,13 +230,43 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
   float* wo = sm;                  // [D][D]
   float* w1 = wo + D * D;          // [D2][D2]
   float* w2 = w1 + D2 * D2;        // [D2][D]
-  float* ct = w2 + D2 * D;         // [D][R]   ctx^T
+  float* wn = w2 + D2 * D;         // [D][96]  the next projection (unused without one)
+  float* vec = wn + D * 96;        // bo[32] | b1[64] | ln_g[64] | ln_b[64] | b2[32] | bn[96]
+  float* ct = vec + LG_TAIL_VEC;   // [D][R]   ctx^T
   float* xt = ct + D * R;          // [D2][R]  (x | message)^T, later h^T
   const int tid = threadIdx.x, rg = tid >> 4, cg = tid & 15;
   const int row0 = blockIdx.x * R;
   for (int e = tid; e < (D * D) >> 2; e += 256) reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(a.wo)[e];
   for (int e = tid; e < (D2 * D2) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.w1)[e];
   for (int e = tid; e < (D2 * D) >> 2; e += 256) reinterpret_cast<float4*>(w2)[e] = reinterpret_cast<const float4*>(a.w2)[e];
+  // Every global read of the kernel is issued here, before the first barrier: with one or two waves per SIMD nothing
+  // hides a load, and the first version fetched its biases, the next projection's weights, the old x and the rotary
+  // table stage by stage — six exposed round trips, 56 % of the wave-cycles waiting (profiles/r3_pmc_lg8_summary.txt)
+  if (a.nn)
+    for (int e = tid; e < (D * a.nn) >> 2; e += 256) reinterpret_cast<float4*>(wn)[e] = reinterpret_cast<const float4*>(a.wn)[e];
+  for (int e = tid; e < LG_TAIL_VEC; e += 256) {
+    float v = 0.f;
+    if (e < 32) v = a.bo[e];
+    else if (e < 96) v = a.b1[e - 32];
+    else if (e < 160) v = a.ln_g[e - 96];
+    else if (e < 224) v = a.ln_b[e - 160];
+    else if (e < 256) v = a.b2[e - 224];
+    else if (a.nn && a.bn && e - 256 < a.nn) v = a.bn[e - 256];
+    vec[e] = v;
+  }
+  // rotary factors of this thread's rows: column pair c = 2 cg + 32 j has frequency (c % hd) / 2, the same for every j
+  // when hd divides 32 (the launcher checks)
+  float rco[RT], rsi[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    rco[r] = 1.f; rsi[r] = 0.f;
+    const int row = row0 + RT * rg + r;
+    if (a.nn && a.cs && row < a.rows) {
+      const int f = ((2 * cg) % a.hd) >> 1;
+      rco[r] = a.cs[(size_t)row * a.hd + f];
+      rsi[r] = a.cs[(size_t)row * a.hd + (a.hd >> 1) + f];
+    }
+  }
   for (int e = tid; e < R * (D >> 2); e += 256) {
     const int r = e >> 3, k = 4 * (e & 7);
     const int row = row0 + r;
@@ -247,6 +279,9 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
     xt[k * R + r] = x.x; xt[(k + 1) * R + r] = x.y; xt[(k + 2) * R + r] = x.z; xt[(k + 3) * R + r] = x.w;
   }
   __syncthreads();
+#if defined(LG_ABL) && LG_ABL == 4
+  if (a.rows > 0) return;
+#endif
   // ---- stage 1: message[64 x 32] = ctx Wo^T + bo -> xt rows D..2D ----
   {
     float acc[RT][2] = {};
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
     }
-    const float b0 = a.bo[2 * cg], b1 = a.bo[2 * cg + 1];
+    const float b0 = vec[2 * cg], b1 = vec[2 * cg + 1];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       xt[(D + 2 * cg) * R + RT * rg + r] = acc[r][0] + b0;
@@ -265,14 +300,24 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
     }
   }
   __syncthreads();
+#if defined(LG_ABL) && LG_ABL == 5
+  if (a.rows > 0) return;
+#endif
   // ---- stage 2: h[64 x 64] = GELU(LayerNorm([x | message] W1^T + b1)) ----
   float h[RT][4];
+  float xold[RT][2];               // this thread's elements of x, for the residual of stage 3
+#pragma unroll
+  for (int r = 0; r < RT; ++r) { xold[r][0] = xt[(2 * cg) * R + RT * rg + r]; xold[r][1] = xt[(2 * cg + 1) * R + RT * rg + r]; }
   {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) h[r][c] = 0.f;
+#if defined(LG_ABL) && (LG_ABL == 2 || LG_ABL == 3)
+    for (int k = 0; k < (a.rows < 0 ? D2 : 1); ++k) {
+#else
     for (int k = 0; k < D2; ++k) {
+#endif
       float xr[RT];
       lg_rows<RT>(&xt[k * R + RT * rg], xr);
 #pragma unroll
@@ -286,7 +331,7 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = 2 * cg + 32 * (c >> 1) + (c & 1);
-      bb[c] = a.b1[col]; gg[c] = a.ln_g[col]; be[c] = a.ln_b[col];
+      bb[c] = vec[32 + col]; gg[c] = vec[96 + col]; be[c] = vec[160 + col];
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -303,18 +348,22 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float y = (h[r][c] - mu) * rs * gg[c] + be[c];
+#if defined(LG_ABL) && LG_ABL == 1
+        h[r][c] = y;
+#else
         h[r][c] = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+#endif
       }
     }
   }
+#if defined(LG_ABL) && LG_ABL == 6
+  if (a.rows > 0) { if (h[0][0] == 123.f) a.x[0] = 0.f; return; }
+#endif
   __syncthreads();                 // every thread is done reading (x | message)^T and W1
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + RT * rg + r] = h[r][c];
-  // the next projection's weights take W1's place (D x nn <= 32 x 96 floats)
-  if (a.nn)
-    for (int e = tid; e < (D * a.nn) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.wn)[e];
   __syncthreads();
   // ---- stage 3: x += h W2^T + b2 ----
   {
@@ -326,16 +375,14 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
     }
-    const float b0 = a.b2[2 * cg], b1 = a.b2[2 * cg + 1];
+    const float b0 = vec[224 + 2 * cg], b1 = vec[224 + 2 * cg + 1];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const int row = row0 + RT * rg + r;
       float2 nx = make_float2(0.f, 0.f);
       if (row < a.rows) {
-        float2* xp = reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg);
-        const float2 old = *xp;
-        nx = make_float2(old.x + acc[r][0] + b0, old.y + acc[r][1] + b1);
-        *xp = nx;
+        nx = make_float2(xold[r][0] + acc[r][0] + b0, xold[r][1] + acc[r][1] + b1);
+        *reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg) = nx;
       }
       if (a.nn) {                    // updated x, transposed, for stage 4 (ctx^T is no longer needed)
         ct[(2 * cg) * R + RT * rg + r] = nx.x;
@@ -343,64 +390,71 @@ __global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
       }
     }
   }
+#if defined(LG_ABL) && LG_ABL == 7
+  if (a.rows > 0) return;
+#endif
   if (!a.nn) return;
   __syncthreads();
   // ---- stage 4: the next projection of the updated rows (same arithmetic and order as lg_linear_kernel) ----
-  {
-    const int nn = a.nn, nj = nn >> 5;
-    float acc[RT][6];
+  // (compile-time width: with nn a run-time value the k loop kept its address arithmetic and three predicated reads per
+  // step and took 3.5 us of the kernel's 25 for a fifth of its FMAs, profiles/r3_ab_lg_tail_stages.txt)
+  auto stage4 = [&](auto njc) {
+    constexpr int NJ = decltype(njc)::value, NN = 32 * NJ;
+    float acc[RT][2 * NJ];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[r][c] = 0.f;
+      for (int c = 0; c < 2 * NJ; ++c) acc[r][c] = 0.f;
+#pragma unroll 8
     for (int k = 0; k < D; ++k) {
       float xr[RT];
       lg_rows<RT>(&ct[k * R + RT * rg], xr);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (j < nj) {
-          const float2 wv = *reinterpret_cast<const float2*>(&w1[k * nn + 2 * cg + 32 * j]);
+      for (int j = 0; j < NJ; ++j) {
+        const float2 wv = *reinterpret_cast<const float2*>(&wn[k * NN + 2 * cg + 32 * j]);
 #pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            acc[r][2 * j] = fmaf(xr[r], wv.x, acc[r][2 * j]);
-            acc[r][2 * j + 1] = fmaf(xr[r], wv.y, acc[r][2 * j + 1]);
-          }
+        for (int r = 0; r < RT; ++r) {
+          acc[r][2 * j] = fmaf(xr[r], wv.x, acc[r][2 * j]);
+          acc[r][2 * j + 1] = fmaf(xr[r], wv.y, acc[r][2 * j + 1]);
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if (j < nj) {
-        const int c = 2 * cg + 32 * j;
-        const float b0 = a.bn ? a.bn[c] : 0.f, b1 = a.bn ? a.bn[c + 1] : 0.f;
-        const bool rot = a.cs && c < a.rot_cols;
-        const int hf = a.hd >> 1, f = rot ? (c % a.hd) >> 1 : 0;
+    for (int j = 0; j < NJ; ++j) {
+      const int c = 2 * cg + 32 * j;
+      const float b0 = vec[256 + c], b1 = vec[256 + c + 1];
+      const bool rot = a.cs && c < a.rot_cols;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const int row = row0 + RT * rg + r;
-          if (row >= a.rows || c >= a.nvalid) continue;
-          float y0 = acc[r][2 * j] + b0, y1 = acc[r][2 * j + 1] + b1;
-          if (rot) {
-            const float co = a.cs[(size_t)row * a.hd + f], si = a.cs[(size_t)row * a.hd + hf + f];
-            const float t0 = y0, t1 = y1;
-            y0 = t0 * co - t1 * si;
-            y1 = t1 * co + t0 * si;
-          }
-          float* o = a.on + (size_t)row * a.nos + c;
-          o[0] = y0;
-          if (c + 1 < a.nvalid) o[1] = y1;
+      for (int r = 0; r < RT; ++r) {
+        const int row = row0 + RT * rg + r;
+        if (row >= a.rows || c >= a.nvalid) continue;
+        float y0 = acc[r][2 * j] + b0, y1 = acc[r][2 * j + 1] + b1;
+        if (rot) {
+          const float co = rco[r], si = rsi[r];
+          const float t0 = y0, t1 = y1;
+          y0 = t0 * co - t1 * si;
+          y1 = t1 * co + t0 * si;
         }
+        float* o = a.on + (size_t)row * a.nos + c;
+        if (c + 1 < a.nvalid) *reinterpret_cast<float2*>(o) = make_float2(y0, y1);      // (nos and c are even)
+        else o[0] = y0;
       }
-  }
+    }
+  };
+  if (a.nn == 96) stage4(std::integral_constant<int, 3>{});
+  else stage4(std::integral_constant<int, 2>{});
 }
 
 int launch_lg_tail(const LgTailArgs& a, hipStream_t s) {
   if (a.D != 32) return -1804;
   if (a.nn && (a.nn != 64 && a.nn != 96)) return -1805;
-  if (a.nn && (!a.wn || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.cs && ((a.hd & 1) || (a.rot_cols & 1))))) return -1805;
+  if (a.nn && (!a.wn || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.cs && ((a.hd & 1) || (a.rot_cols & 1) || 32 % a.hd)) || (a.nos & 1))) return -1805;
   static const int forced = getenv("KP2D_LG_TAIL_RT") ? atoi(getenv("KP2D_LG_TAIL_RT")) : 0;
   const int rt = forced ? forced : a.rows >= 64 * 256 ? 4 : a.rows >= 32 * 256 ? 2 : 1;      // (8 pairs x 2048 rows: 0.547 / 0.595 / 0.569 ms per forward at RT = 4 / 2 / 1)
-  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + (32 + 64) * 16 * rt) * sizeof(float);
+  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + 32 * 96 + LG_TAIL_VEC + (32 + 64) * 16 * rt) * sizeof(float);
+  static PerDeviceOnce once[3];       // (67 KB at RT = 4: above the 64 KB a kernel gets without opting in)
+  const void* fn = rt == 4 ? (const void*)&lg_tail_kernel<4> : rt == 2 ? (const void*)&lg_tail_kernel<2> : (const void*)&lg_tail_kernel<1>;
+  if (int e = lds_opt_in(once[rt >> 1], fn)) return e;
   const dim3 grid((a.rows + 16 * rt - 1) / (16 * rt));
   switch (rt) {
     case 4: hipLaunchKernelGGL(lg_tail_kernel<4>, grid, dim3(256), lds, s, a); break;
