@@ -165,15 +165,16 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s);
 
 // fused tail of a Self/CrossBlock for D = 32: x += ffn(cat[x, out_proj(ctx)])  (lightglue.py:260-261 / :322-326)
 struct LgTailArgs {
-  float* x; const float* ctx;           // [rows][D] in place / attention context
-  const float* wo; const float* bo;      // out_proj / to_out: W^T [D][D], bias
-  const float* w1; const float* b1;      // ffn.0: W^T [2D][2D], bias
+  float* x; const float* ctx;           // [rows][D] in place / attention context (null: projection only)
+  // split-fp16 matrix-core images of W (lightglue_api.cpp mfma_image()) and fp32 biases
+  const void* io; const float* bo;       // out_proj / to_out  [D -> D]
+  const void* i1; const float* b1;       // ffn.0              [2D -> 2D]
   const float* ln_g; const float* ln_b;  // ffn.1
-  const float* w2; const float* b2;      // ffn.3: W^T [2D][D], bias
+  const void* i2; const float* b2;       // ffn.3              [2D -> D]
   int rows, D;
   // optional: the NEXT token-wise projection of the updated x in the same launch (the cross block's [to_qk | to_v], the
   // next layer's Wqkv with its rotary epilogue, or the final projection): out[row][0..nvalid) = x W^T + b
-  const float* wn = nullptr; const float* bn = nullptr;   // W^T [D][nn] (nn = 64 or 96, padded), bias [nn]
+  const void* in = nullptr; const float* bn = nullptr;    // image [D -> nn] (nn = 64 or 96, padded), bias [nn]
   float* on = nullptr; int nn = 0, nos = 0, nvalid = 0;   // output, its row stride, columns stored
   const float* cs = nullptr; int hd = 0, rot_cols = 0;    // rotary: per-row cos | sin, head dim, leading columns that rotate
 };

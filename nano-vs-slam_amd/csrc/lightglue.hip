@@ -207,261 +207,219 @@ int launch_lg_linear(const LgLinArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-constexpr int LG_TAIL_VEC = 352;      // floats of bias / LayerNorm vectors staged by lg_tail_kernel
-template <int RT> __device__ __forceinline__ void lg_rows(const float* p, float (&x)[RT]) {      // RT adjacent LDS floats
-  if constexpr (RT == 4) { const float4 v = *reinterpret_cast<const float4*>(p); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
-  else if constexpr (RT == 2) { const float2 v = *reinterpret_cast<const float2*>(p); x[0] = v.x; x[1] = v.y; }
-  else x[0] = *p;
-}
+constexpr int LG_TAIL_VEC = 352;      // floats of bias / LayerNorm vectors staged by lg_tail_mfma_kernel
 
 // ---------------------------------------------------------------------------------------------
-// Fused block tail for D = 32: message = out_proj(ctx); h = GELU(LayerNorm(W1 [x | message] + b1)); x += W2 h + b2.
-// All three products are row-local, so one workgroup carries its 16 RT rows through them with the intermediate tiles
-// (transposed, [k][row]) in LDS: 3 launches and 2 HBM round trips of the message / hidden tensors less per block.
-// Thread mapping of lg_linear_kernel (thread = RT rows x column pairs {2cg + 32j, +1}); a row's arithmetic does not
-// depend on RT.  One image pair is 2048 rows: at 64 rows per workgroup (RT = 4) that was 32 workgroups walking the
-// 192 k-steps of the four products on 32 of the 256 CUs, 20 us per launch (RT = 1: 128 workgroups, 0.404 -> 0.348 ms per
-// forward, profiles/r3_lightglue_kernels.txt).
+// Fused block tail for D = 32: message = out_proj(ctx); h = GELU(LayerNorm(W1 [x | message] + b1)); x += W2 h + b2;
+// then, optionally, the NEXT token-wise projection of the updated rows (the cross block's [to_qk | to_v], the next
+// layer's Wqkv with rotary, the final projection).  All of it is row-local: one launch instead of five, and no HBM
+// round trip of the message / hidden tensors.
+// On the matrix cores.  A wave owns 16 rows and never meets another wave after the weights are
+// staged.  Every product is computed transposed, Y^T = W X^T, with v_mfma_f32_16x16x32_f16 in split-fp16 arithmetic
+// (x w = xh wh + xh wl + xl wh, fp32 accumulation: fp32-grade, as the attention products): W tiles are the A operand
+// (pre-split images, lightglue_api.cpp mfma_image()), the activations the B operand.  An accumulator tile holds, for
+// the lane's row (lane % 16), features 16 t + 4 (lane / 16) + r; the images order their k elements exactly that way,
+// so an output is the next product's B operand after a split in registers: no LDS round trip, no barrier, no k loop.
+// (The first version did these products with fp32 FMAs, transposed tiles in LDS: 192 dependent k steps per row group,
+// 8 us (16-row groups) to 18 us (64-row groups) of compute behind a 5-7 us launch + staging floor,
+// profiles/r3_ab_lg_tail_stages.txt; matcher 0.55 -> 0.45 ms for 8 pairs, 0.24 -> 0.20 ms for one.)
+// a.ctx == nullptr: projection only (the first layer's Wqkv) — x goes straight to stage 4.
 // ---------------------------------------------------------------------------------------------
-template <int RT>   // rows per thread: a workgroup carries 16 * RT rows
-__global__ __launch_bounds__(256) void lg_tail_kernel(const LgTailArgs a) {
-  constexpr int D = 32, D2 = 64, R = 16 * RT;
+typedef _Float16 lh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lh2 __attribute__((ext_vector_type(2)));
+typedef float lf4 __attribute__((ext_vector_type(4)));
+typedef float lf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lg_split8(const float* x, lh8& hi, lh8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const lf2 v = {x[j], x[j + 1]};
+    const lh2 h = __builtin_convertvector(v, lh2);
+    unsigned l;       // lo = fp16(x - float(hi)), three instructions per two values (attention.hip att_split2)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x[j]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x[j + 1]));
+    const lh2 lw = __builtin_bit_cast(lh2, l);
+    hi[j] = h[0]; hi[j + 1] = h[1]; lo[j] = lw[0]; lo[j + 1] = lw[1];
+  }
+}
+// acc += W(t, s) . b for one image block (hi at +0, lo at +512 halves): small terms first
+__device__ __forceinline__ lf4 lg_mma(const _Float16* blk, int lane, const lh8 bh, const lh8 bl, lf4 acc) {
+  const lh8 wh = *reinterpret_cast<const lh8*>(blk + lane * 8);
+  const lh8 wl = *reinterpret_cast<const lh8*>(blk + 512 + lane * 8);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc, 0, 0, 0);
+}
+
+constexpr int LG_IMG_O = 2 * 1024, LG_IMG_1 = 8 * 1024, LG_IMG_2 = 4 * 1024, LG_IMG_N = 6 * 1024;      // halves
+
+template <int NW>   // waves per workgroup (16 rows each)
+__global__ __launch_bounds__(64 * NW) void lg_tail_mfma_kernel(const LgTailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* wo = sm;                  // [D][D]
-  float* w1 = wo + D * D;          // [D2][D2]
-  float* w2 = w1 + D2 * D2;        // [D2][D]
-  float* wn = w2 + D2 * D;         // [D][96]  the next projection (unused without one)
-  float* vec = wn + D * 96;        // bo[32] | b1[64] | ln_g[64] | ln_b[64] | b2[32] | bn[96]
-  float* ct = vec + LG_TAIL_VEC;   // [D][R]   ctx^T
-  float* xt = ct + D * R;          // [D2][R]  (x | message)^T, later h^T
-  const int tid = threadIdx.x, rg = tid >> 4, cg = tid & 15;
-  const int row0 = blockIdx.x * R;
-  for (int e = tid; e < (D * D) >> 2; e += 256) reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(a.wo)[e];
-  for (int e = tid; e < (D2 * D2) >> 2; e += 256) reinterpret_cast<float4*>(w1)[e] = reinterpret_cast<const float4*>(a.w1)[e];
-  for (int e = tid; e < (D2 * D) >> 2; e += 256) reinterpret_cast<float4*>(w2)[e] = reinterpret_cast<const float4*>(a.w2)[e];
-  // Every global read of the kernel is issued here, before the first barrier: with one or two waves per SIMD nothing
-  // hides a load, and the first version fetched its biases, the next projection's weights, the old x and the rotary
-  // table stage by stage — six exposed round trips, 56 % of the wave-cycles waiting (profiles/r3_pmc_lg8_summary.txt)
-  if (a.nn)
-    for (int e = tid; e < (D * a.nn) >> 2; e += 256) reinterpret_cast<float4*>(wn)[e] = reinterpret_cast<const float4*>(a.wn)[e];
-  for (int e = tid; e < LG_TAIL_VEC; e += 256) {
+  _Float16* io = reinterpret_cast<_Float16*>(sm);
+  _Float16* i1 = io + LG_IMG_O;
+  _Float16* i2 = i1 + LG_IMG_1;
+  _Float16* in = i2 + LG_IMG_2;
+  float* vec = reinterpret_cast<float*>(in + LG_IMG_N);      // bo[32] | b1[64] | ln_g[64] | ln_b[64] | b2[32] | bn[96]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = (blockIdx.x * NW + wave) * 16 + (lane & 15);
+  const bool ok = row < a.rows;
+  const bool full = a.ctx != nullptr;
+  // every global read of the kernel, before the only barrier
+  auto copy16 = [&](_Float16* dst, const void* src, int halves) {
+    for (int e = tid; e < halves >> 3; e += 64 * NW) reinterpret_cast<uint4*>(dst)[e] = reinterpret_cast<const uint4*>(src)[e];
+  };
+  if (full) { copy16(io, a.io, LG_IMG_O); copy16(i1, a.i1, LG_IMG_1); copy16(i2, a.i2, LG_IMG_2); }
+  if (a.nn) copy16(in, a.in, a.nn * 64);                     // (nn / 16 tiles of 1024 halves)
+  for (int e = tid; e < LG_TAIL_VEC; e += 64 * NW) {
     float v = 0.f;
-    if (e < 32) v = a.bo[e];
-    else if (e < 96) v = a.b1[e - 32];
-    else if (e < 160) v = a.ln_g[e - 96];
-    else if (e < 224) v = a.ln_b[e - 160];
-    else if (e < 256) v = a.b2[e - 224];
-    else if (a.nn && a.bn && e - 256 < a.nn) v = a.bn[e - 256];
+    if (e < 256) {
+      if (full) v = e < 32 ? a.bo[e] : e < 96 ? a.b1[e - 32] : e < 160 ? a.ln_g[e - 96] : e < 224 ? a.ln_b[e - 160] : a.b2[e - 224];
+    } else if (a.nn && a.bn && e - 256 < a.nn) {
+      v = a.bn[e - 256];
+    }
     vec[e] = v;
   }
-  // rotary factors of this thread's rows: column pair c = 2 cg + 32 j has frequency (c % hd) / 2, the same for every j
-  // when hd divides 32 (the launcher checks)
-  float rco[RT], rsi[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    rco[r] = 1.f; rsi[r] = 0.f;
-    const int row = row0 + RT * rg + r;
-    if (a.nn && a.cs && row < a.rows) {
-      const int f = ((2 * cg) % a.hd) >> 1;
-      rco[r] = a.cs[(size_t)row * a.hd + f];
-      rsi[r] = a.cs[(size_t)row * a.hd + (a.hd >> 1) + f];
+  // this lane's eight features of its row: 4 g .. 4 g + 3 and 16 + 4 g .. + 3 (the accumulator order)
+  float xv[8] = {}, cv[8] = {};
+  if (ok) {
+    const float* xp = a.x + (size_t)row * 32 + 4 * g;
+    *reinterpret_cast<float4*>(&xv[0]) = *reinterpret_cast<const float4*>(xp);
+    *reinterpret_cast<float4*>(&xv[4]) = *reinterpret_cast<const float4*>(xp + 16);
+    if (full) {
+      const float* cp = a.ctx + (size_t)row * 32 + 4 * g;
+      *reinterpret_cast<float4*>(&cv[0]) = *reinterpret_cast<const float4*>(cp);
+      *reinterpret_cast<float4*>(&cv[4]) = *reinterpret_cast<const float4*>(cp + 16);
     }
   }
-  for (int e = tid; e < R * (D >> 2); e += 256) {
-    const int r = e >> 3, k = 4 * (e & 7);
-    const int row = row0 + r;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), x = c;
-    if (row < a.rows) {
-      c = *reinterpret_cast<const float4*>(a.ctx + (size_t)row * D + k);
-      x = *reinterpret_cast<const float4*>(a.x + (size_t)row * D + k);
-    }
-    ct[k * R + r] = c.x; ct[(k + 1) * R + r] = c.y; ct[(k + 2) * R + r] = c.z; ct[(k + 3) * R + r] = c.w;
-    xt[k * R + r] = x.x; xt[(k + 1) * R + r] = x.y; xt[(k + 2) * R + r] = x.z; xt[(k + 3) * R + r] = x.w;
-  }
-  __syncthreads();
-#if defined(LG_ABL) && LG_ABL == 4
-  if (a.rows > 0) return;
-#endif
-  // ---- stage 1: message[64 x 32] = ctx Wo^T + bo -> xt rows D..2D ----
-  {
-    float acc[RT][2] = {};
-    for (int k = 0; k < D; ++k) {
-      float xr[RT];
-      lg_rows<RT>(&ct[k * R + RT * rg], xr);
-      const float2 wv = *reinterpret_cast<const float2*>(&wo[k * D + 2 * cg]);
+  // rotary factors of the lane's two column pairs: column 16 t + 4 g + 2 p has frequency ((4 g + 2 p) % hd) / 2 for
+  // every tile t (hd divides 16)
+  float rco[2] = {1.f, 1.f}, rsi[2] = {0.f, 0.f};
+  if (a.nn && a.cs && ok) {
 #pragma unroll
-      for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
-    }
-    const float b0 = vec[2 * cg], b1 = vec[2 * cg + 1];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      xt[(D + 2 * cg) * R + RT * rg + r] = acc[r][0] + b0;
-      xt[(D + 2 * cg + 1) * R + RT * rg + r] = acc[r][1] + b1;
+    for (int p = 0; p < 2; ++p) {
+      const int f = ((4 * g + 2 * p) % a.hd) >> 1;
+      rco[p] = a.cs[(size_t)row * a.hd + f];
+      rsi[p] = a.cs[(size_t)row * a.hd + (a.hd >> 1) + f];
     }
   }
   __syncthreads();
-#if defined(LG_ABL) && LG_ABL == 5
-  if (a.rows > 0) return;
-#endif
-  // ---- stage 2: h[64 x 64] = GELU(LayerNorm([x | message] W1^T + b1)) ----
-  float h[RT][4];
-  float xold[RT][2];               // this thread's elements of x, for the residual of stage 3
+  auto bias4 = [&](int off) { return *reinterpret_cast<const lf4*>(&vec[off + 4 * g]); };
+  float xn[8];
+  if (full) {
+    // ---- stage 1: message = ctx Wo^T + bo ----
+    lh8 bh, bl;
+    float msg[8];
+    lg_split8(cv, bh, bl);
 #pragma unroll
-  for (int r = 0; r < RT; ++r) { xold[r][0] = xt[(2 * cg) * R + RT * rg + r]; xold[r][1] = xt[(2 * cg + 1) * R + RT * rg + r]; }
-  {
+    for (int t = 0; t < 2; ++t) {
+      const lf4 acc = lg_mma(io + t * 1024, lane, bh, bl, bias4(16 * t));
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) h[r][c] = 0.f;
-#if defined(LG_ABL) && (LG_ABL == 2 || LG_ABL == 3)
-    for (int k = 0; k < (a.rows < 0 ? D2 : 1); ++k) {
-#else
-    for (int k = 0; k < D2; ++k) {
-#endif
-      float xr[RT];
-      lg_rows<RT>(&xt[k * R + RT * rg], xr);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float2 wv = *reinterpret_cast<const float2*>(&w1[k * D2 + 2 * cg + 32 * j]);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) { h[r][2 * j] = fmaf(xr[r], wv.x, h[r][2 * j]); h[r][2 * j + 1] = fmaf(xr[r], wv.y, h[r][2 * j + 1]); }
-      }
+      for (int r = 0; r < 4; ++r) msg[4 * t + r] = acc[r];
     }
-    float bb[4], gg[4], be[4];
+    // ---- stage 2: h = GELU(LayerNorm([x | message] W1^T + b1)) ----
+    lh8 xh, xl, mh, ml;
+    lg_split8(xv, xh, xl);
+    lg_split8(msg, mh, ml);
+    float h[16];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int col = 2 * cg + 32 * (c >> 1) + (c & 1);
-      bb[c] = vec[32 + col]; gg[c] = vec[96 + col]; be[c] = vec[160 + col];
+    for (int t = 0; t < 4; ++t) {
+      lf4 acc = lg_mma(i1 + (2 * t) * 1024, lane, xh, xl, bias4(32 + 16 * t));
+      acc = lg_mma(i1 + (2 * t + 1) * 1024, lane, mh, ml, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[4 * t + r] = acc[r];
     }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
+    {
       float s = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { h[r][c] += bb[c]; s += h[r][c]; }
-      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
-      const float mu = s * (1.f / D2);
+      for (int c = 0; c < 16; ++c) s += h[c];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mu = s * (1.f / 64.f);
       float q = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { const float d = h[r][c] - mu; q = fmaf(d, d, q); }
-      for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
-      const float rs = 1.f / sqrtf(q * (1.f / D2) + 1e-5f);
+      for (int c = 0; c < 16; ++c) { const float d = h[c] - mu; q = fmaf(d, d, q); }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rs = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float y = (h[r][c] - mu) * rs * gg[c] + be[c];
-#if defined(LG_ABL) && LG_ABL == 1
-        h[r][c] = y;
-#else
-        h[r][c] = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
-#endif
+      for (int t = 0; t < 4; ++t) {
+        const lf4 gg = bias4(96 + 16 * t), be = bias4(160 + 16 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = (h[4 * t + r] - mu) * rs * gg[r] + be[r];
+          h[4 * t + r] = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+        }
       }
     }
+    // ---- stage 3: x += h W2^T + b2 ----
+    lh8 hh[2], hl[2];
+    lg_split8(&h[0], hh[0], hl[0]);
+    lg_split8(&h[8], hh[1], hl[1]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      lf4 acc = lg_mma(i2 + (2 * t) * 1024, lane, hh[0], hl[0], bias4(224 + 16 * t));
+      acc = lg_mma(i2 + (2 * t + 1) * 1024, lane, hh[1], hl[1], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xn[4 * t + r] = xv[4 * t + r] + acc[r];
+    }
+    if (ok) {
+      float* xp = a.x + (size_t)row * 32 + 4 * g;
+      *reinterpret_cast<float4*>(xp) = *reinterpret_cast<const float4*>(&xn[0]);
+      *reinterpret_cast<float4*>(xp + 16) = *reinterpret_cast<const float4*>(&xn[4]);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xn[c] = xv[c];
   }
-#if defined(LG_ABL) && LG_ABL == 6
-  if (a.rows > 0) { if (h[0][0] == 123.f) a.x[0] = 0.f; return; }
-#endif
-  __syncthreads();                 // every thread is done reading (x | message)^T and W1
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) xt[(2 * cg + 32 * (c >> 1) + (c & 1)) * R + RT * rg + r] = h[r][c];
-  __syncthreads();
-  // ---- stage 3: x += h W2^T + b2 ----
-  {
-    float acc[RT][2] = {};
-    for (int k = 0; k < D2; ++k) {
-      float xr[RT];
-      lg_rows<RT>(&xt[k * R + RT * rg], xr);
-      const float2 wv = *reinterpret_cast<const float2*>(&w2[k * D + 2 * cg]);
-#pragma unroll
-      for (int r = 0; r < RT; ++r) { acc[r][0] = fmaf(xr[r], wv.x, acc[r][0]); acc[r][1] = fmaf(xr[r], wv.y, acc[r][1]); }
-    }
-    const float b0 = vec[224 + 2 * cg], b1 = vec[224 + 2 * cg + 1];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      const int row = row0 + RT * rg + r;
-      float2 nx = make_float2(0.f, 0.f);
-      if (row < a.rows) {
-        nx = make_float2(xold[r][0] + acc[r][0] + b0, xold[r][1] + acc[r][1] + b1);
-        *reinterpret_cast<float2*>(a.x + (size_t)row * D + 2 * cg) = nx;
-      }
-      if (a.nn) {                    // updated x, transposed, for stage 4 (ctx^T is no longer needed)
-        ct[(2 * cg) * R + RT * rg + r] = nx.x;
-        ct[(2 * cg + 1) * R + RT * rg + r] = nx.y;
-      }
-    }
-  }
-#if defined(LG_ABL) && LG_ABL == 7
-  if (a.rows > 0) return;
-#endif
   if (!a.nn) return;
-  __syncthreads();
-  // ---- stage 4: the next projection of the updated rows (same arithmetic and order as lg_linear_kernel) ----
-  // (compile-time width: with nn a run-time value the k loop kept its address arithmetic and three predicated reads per
-  // step and took 3.5 us of the kernel's 25 for a fifth of its FMAs, profiles/r3_ab_lg_tail_stages.txt)
-  auto stage4 = [&](auto njc) {
-    constexpr int NJ = decltype(njc)::value, NN = 32 * NJ;
-    float acc[RT][2 * NJ];
+  // ---- stage 4: the next projection of the updated rows, rotary on its leading columns ----
+  lh8 nh, nl;
+  lg_split8(xn, nh, nl);
+  const int nt = a.nn >> 4;
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+  for (int t = 0; t < 6; ++t) {
+    if (t >= nt) break;
+    lf4 y = lg_mma(in + t * 1024, lane, nh, nl, bias4(256 + 16 * t));
+    const int c = 16 * t + 4 * g;
+    if (a.cs && c < a.rot_cols) {
 #pragma unroll
-      for (int c = 0; c < 2 * NJ; ++c) acc[r][c] = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < D; ++k) {
-      float xr[RT];
-      lg_rows<RT>(&ct[k * R + RT * rg], xr);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const float2 wv = *reinterpret_cast<const float2*>(&wn[k * NN + 2 * cg + 32 * j]);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          acc[r][2 * j] = fmaf(xr[r], wv.x, acc[r][2 * j]);
-          acc[r][2 * j + 1] = fmaf(xr[r], wv.y, acc[r][2 * j + 1]);
-        }
+      for (int p = 0; p < 2; ++p) {
+        const float t0 = y[2 * p], t1 = y[2 * p + 1];
+        y[2 * p] = t0 * rco[p] - t1 * rsi[p];        // t*cos + rotate_half(t)*sin, rotate_half = (-t1, t0)
+        y[2 * p + 1] = t1 * rco[p] + t0 * rsi[p];
       }
     }
+    if (!ok) continue;
+    float* o = a.on + (size_t)row * a.nos + c;
+    if (c + 3 < a.nvalid) {
+      *reinterpret_cast<lf4*>(o) = y;
+    } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int c = 2 * cg + 32 * j;
-      const float b0 = vec[256 + c], b1 = vec[256 + c + 1];
-      const bool rot = a.cs && c < a.rot_cols;
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const int row = row0 + RT * rg + r;
-        if (row >= a.rows || c >= a.nvalid) continue;
-        float y0 = acc[r][2 * j] + b0, y1 = acc[r][2 * j + 1] + b1;
-        if (rot) {
-          const float co = rco[r], si = rsi[r];
-          const float t0 = y0, t1 = y1;
-          y0 = t0 * co - t1 * si;
-          y1 = t1 * co + t0 * si;
-        }
-        float* o = a.on + (size_t)row * a.nos + c;
-        if (c + 1 < a.nvalid) *reinterpret_cast<float2*>(o) = make_float2(y0, y1);      // (nos and c are even)
-        else o[0] = y0;
-      }
+      for (int r = 0; r < 4; ++r)
+        if (c + r < a.nvalid) o[r] = y[r];
     }
-  };
-  if (a.nn == 96) stage4(std::integral_constant<int, 3>{});
-  else stage4(std::integral_constant<int, 2>{});
+  }
 }
 
 int launch_lg_tail(const LgTailArgs& a, hipStream_t s) {
   if (a.D != 32) return -1804;
   if (a.nn && (a.nn != 64 && a.nn != 96)) return -1805;
-  if (a.nn && (!a.wn || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.cs && ((a.hd & 1) || (a.rot_cols & 1) || 32 % a.hd)) || (a.nos & 1))) return -1805;
-  static const int forced = getenv("KP2D_LG_TAIL_RT") ? atoi(getenv("KP2D_LG_TAIL_RT")) : 0;
-  const int rt = forced ? forced : a.rows >= 64 * 256 ? 4 : a.rows >= 32 * 256 ? 2 : 1;      // (8 pairs x 2048 rows: 0.547 / 0.595 / 0.569 ms per forward at RT = 4 / 2 / 1)
-  const size_t lds = (size_t)(32 * 32 + 64 * 64 + 64 * 32 + 32 * 96 + LG_TAIL_VEC + (32 + 64) * 16 * rt) * sizeof(float);
-  static PerDeviceOnce once[3];       // (67 KB at RT = 4: above the 64 KB a kernel gets without opting in)
-  const void* fn = rt == 4 ? (const void*)&lg_tail_kernel<4> : rt == 2 ? (const void*)&lg_tail_kernel<2> : (const void*)&lg_tail_kernel<1>;
-  if (int e = lds_opt_in(once[rt >> 1], fn)) return e;
-  const dim3 grid((a.rows + 16 * rt - 1) / (16 * rt));
-  switch (rt) {
-    case 4: hipLaunchKernelGGL(lg_tail_kernel<4>, grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(lg_tail_kernel<2>, grid, dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL(lg_tail_kernel<1>, grid, dim3(256), lds, s, a); break;
-    default: return -1806;
-  }
+  if (a.nn && (!a.in || !a.on || a.nvalid < 1 || a.nvalid > a.nn || (a.nos & 3) ||
+               (a.cs && ((a.hd & 1) || 16 % a.hd || (a.rot_cols & 15)))))
+    return -1805;
+  if (a.ctx && (!a.io || !a.i1 || !a.i2)) return -1807;
+  if (!a.ctx && !a.nn) return -1807;
+  // four waves per workgroup also at one image pair (2048 rows = 32 workgroups): one-wave workgroups spread wider but
+  // each stages the 42 KB of operands with 64 lanes — 0.236 vs 0.204 ms per forward
+  static const int forced = getenv("KP2D_LG_TAIL_NW") ? atoi(getenv("KP2D_LG_TAIL_NW")) : 0;
+  const int nw = forced ? forced : 4;
+  const size_t lds = (size_t)(LG_IMG_O + LG_IMG_1 + LG_IMG_2 + LG_IMG_N) * 2 + LG_TAIL_VEC * sizeof(float);
+  const dim3 grid((a.rows + 16 * nw - 1) / (16 * nw));
+  if (nw == 4) hipLaunchKernelGGL(lg_tail_mfma_kernel<4>, grid, dim3(256), lds, s, a);
+  else if (nw == 1) hipLaunchKernelGGL(lg_tail_mfma_kernel<1>, grid, dim3(64), lds, s, a);
+  else return -1806;
   return (int)hipGetLastError();
 }
 
@@ -483,9 +441,12 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
   m = mm;
 }
 
+constexpr int LG_TP = 68;      // pitch (floats) of the LDS tile that global rows go through
+
 // thread (ty = tid/16, tx = tid%16) owns rows i0 + 4 ty + r, columns j0 + 4 tx + c of the tile
 __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   __shared__ __attribute__((aligned(16))) float at[64 * 64], bt[64 * 64];   // [k][row]
+  __shared__ float tile[64 * LG_TP];
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, D = a.D, M = a.M, N = a.N;
   const float* f0 = a.fz + (size_t)b * M * a.fs;
@@ -507,14 +468,16 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(ar[r], br[c], acc[r][c]);
   }
-  float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
+  // The rows of scores are N + 1 floats: no 16-byte alignment, and a thread's 4 x 4 block stored directly is sixteen
+  // 4-byte stores at a 16-byte lane stride (a quarter of every 64-byte segment used).  Through an LDS tile instead:
+  // every wave store is 64 consecutive floats of one row.
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      tile[(4 * ty + r) * LG_TP + 4 * tx + c] = acc[r][c];
       const int i = i0 + 4 * ty + r, j = j0 + 4 * tx + c;
-      if (i < M && j < N) sc[(size_t)i * (N + 1) + j] = acc[r][c];
-      else acc[r][c] = -INFINITY;            // outside the inner block: no weight in the sums below
+      if (i >= M || j >= N) acc[r][c] = -INFINITY;            // outside the inner block: no weight in the sums below
     }
   // rows: the 16 threads of a row group are 16 adjacent lanes
   const int TN = gridDim.x, TM = gridDim.y;
@@ -539,6 +502,15 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   float* cm = at;                            // [4 waves][64 columns]
   float* cs = at + 256;
   const int wave = tid >> 6, q = (tid >> 4) & 3;
+  {
+    float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
+    const int j = j0 + (tid & 63);
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + 16 * wave + r;
+      if (i < M && j < N) sc[(size_t)i * (N + 1) + j] = tile[(16 * wave + r) * LG_TP + (tid & 63)];
+    }
+  }
   float m4[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -585,6 +557,7 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   __shared__ float s_base[64], s_col[64], s_ls1[64];
   __shared__ float s_cm[4][64];
   __shared__ int s_ci[4][64];
+  __shared__ float tile[64 * LG_TP];
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, M = a.M, N = a.N, TN = gridDim.x, TM = gridDim.y;
   float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
@@ -622,6 +595,14 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   } else if (tid == 128 && blockIdx.x == 0 && blockIdx.y == 0) {
     sc[(size_t)M * (N + 1) + N] = 0.f;
   }
+  {   // sim tile in: whole 64-float row segments per wave load (see lg_sim_kernel)
+    const int j = j0 + (tid & 63), w = tid >> 6;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + 16 * w + r;
+      tile[(16 * w + r) * LG_TP + (tid & 63)] = (i < M && j < N) ? sc[(size_t)i * (N + 1) + j] : 0.f;
+    }
+  }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
   float v[4][4];
@@ -634,7 +615,7 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
       const int j = j0 + 4 * tx + c;
       float x = -INFINITY;
       if (i < M && j < N) {
-        float* p = sc + (size_t)i * (N + 1) + j;
+        float* p = &tile[(4 * ty + r) * LG_TP + 4 * tx + c];
         x = 2.f * *p + base - s_col[4 * tx + c] + s_ls1[4 * tx + c];
         *p = x;
       }
@@ -678,6 +659,14 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
     if (q == 0) { s_cm[wave][4 * tx + c] = mx; s_ci[wave][4 * tx + c] = arg; }
   }
   __syncthreads();
+  {   // final tile out
+    const int j = j0 + (tid & 63);
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + 16 * wave + r;
+      if (i < M && j < N) sc[(size_t)i * (N + 1) + j] = tile[(16 * wave + r) * LG_TP + (tid & 63)];
+    }
+  }
   if (tid < 64 && j0 + tid < N) {
     float mx = s_cm[0][tid];
     int arg = s_ci[0][tid];

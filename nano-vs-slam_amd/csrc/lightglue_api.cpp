@@ -45,7 +45,8 @@ struct Spec {
 };
 
 // one packed linear layer: W^T [K][nout] then bias [nout] (nout padded to a multiple of 32)
-struct Lin { size_t w = 0, b = 0; int K = 0, nout = 0; };
+// mf: the same matrix as split-fp16 matrix-core operand tiles (mfma_image), K * nout * 4 bytes, when K % 32 == 0
+struct Lin { size_t w = 0, b = 0, mf = 0; int K = 0, nout = 0; };
 struct Ffn { Lin l0, l3; size_t g = 0, be = 0; };
 struct Layer { Lin qkv, out_proj, qkv_x, to_out; Ffn fs, fc; };
 
@@ -106,7 +107,11 @@ void describe(kp2d_lg* m) {
 
   size_t off = 0;
   auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats, ALIGN / 4); return o; };
-  auto lin = [&](int K, int nout) { Lin l; l.K = K; l.nout = pad32(nout); l.w = take((size_t)K * l.nout); l.b = take(l.nout); return l; };
+  auto lin = [&](int K, int nout) {
+    Lin l; l.K = K; l.nout = pad32(nout); l.w = take((size_t)K * l.nout); l.b = take(l.nout);
+    if (K % 32 == 0) l.mf = take((size_t)K * l.nout);
+    return l;
+  };
   auto ffn = [&]() { Ffn f; f.l0 = lin(2 * d, 2 * d); f.g = take(2 * d); f.be = take(2 * d); f.l3 = lin(2 * d, d); return f; };
   if (din != d) m->input_proj = lin(din, d);
   m->wr = take(hd);
@@ -129,6 +134,30 @@ void put_linear(std::vector<float>& blob, const Lin& l, const std::vector<float>
     for (int k = 0; k < l.K; ++k) blob[l.w + (size_t)k * l.nout + c] = w[(size_t)r * l.K + k] * scale;
     if (b) blob[l.b + c] = (*b)[r] * scale;
   }
+}
+
+// W^T [K][nout] (already in the blob) -> the A operands of v_mfma_f32_16x16x32_f16 for Y^T = W X^T, one 2-KB block
+// per (16-feature tile t, 32-wide k step s): [hi | lo][lane][8 halves].  Lane l = (feature 16t + l%16, group g = l/16);
+// its element j multiplies input feature 32s + 4g + j (j < 4) or 32s + 16 + 4g + (j - 4): the order in which the lanes
+// of the PREVIOUS product's accumulator tiles (feature 16t' + 4g + r of row l%16) hold a row — a product's output is
+// the next product's B operand without leaving its registers (lightglue.hip lg_tail_kernel).
+void mfma_image(std::vector<float>& blob, const Lin& l) {
+  if (!l.mf) return;
+  _Float16* img = reinterpret_cast<_Float16*>(blob.data() + l.mf);
+  const int KS = l.K / 32;
+  for (int t = 0; t < l.nout / 16; ++t)
+    for (int s = 0; s < KS; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int n = 16 * t + (lane & 15), g = lane >> 4;
+          const int k = 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+          const float w = blob[l.w + (size_t)k * l.nout + n];
+          const _Float16 hi = (_Float16)w;
+          const _Float16 lo = (_Float16)(w - (float)hi);
+          _Float16* blk = img + (size_t)(t * KS + s) * 1024;
+          blk[lane * 8 + j] = hi;
+          blk[512 + lane * 8 + j] = lo;
+        }
 }
 
 int pack(kp2d_lg* m, std::vector<float>& blob) {
@@ -165,6 +194,9 @@ int pack(kp2d_lg* m, std::vector<float>& blob) {
   const std::string a = "log_assignment." + std::to_string(n - 1);
   put_linear(blob, m->final, H(m, a + ".final_proj.weight"), &H(m, a + ".final_proj.bias"), d, 0, 1.f / std::pow((float)d, 0.25f));
   put_linear(blob, m->final, H(m, a + ".matchability.weight"), &H(m, a + ".matchability.bias"), 1, d, 1.f);
+  for (const Layer& L : m->layers)
+    for (const Lin* l : {&L.qkv, &L.out_proj, &L.qkv_x, &L.to_out, &L.fs.l0, &L.fs.l3, &L.fc.l0, &L.fc.l3}) mfma_image(blob, *l);
+  mfma_image(blob, m->final);
   return KP2D_OK;
 }
 
@@ -323,10 +355,10 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
   auto tail = [&](const Lin& proj, const Ffn& f, const char* what, const Lin* next, float* nout, int nos, int nvalid,
                   bool rotary) -> int {
     LgTailArgs t{};
-    t.x = X; t.ctx = CTX; t.wo = blob + proj.w; t.bo = blob + proj.b; t.w1 = blob + f.l0.w; t.b1 = blob + f.l0.b;
-    t.ln_g = blob + f.g; t.ln_b = blob + f.be; t.w2 = blob + f.l3.w; t.b2 = blob + f.l3.b; t.rows = R; t.D = d;
+    t.x = X; t.ctx = CTX; t.io = blob + proj.mf; t.bo = blob + proj.b; t.i1 = blob + f.l0.mf; t.b1 = blob + f.l0.b;
+    t.ln_g = blob + f.g; t.ln_b = blob + f.be; t.i2 = blob + f.l3.mf; t.b2 = blob + f.l3.b; t.rows = R; t.D = d;
     if (next) {
-      t.wn = blob + next->w; t.bn = blob + next->b; t.on = nout; t.nn = next->nout; t.nos = nos; t.nvalid = nvalid;
+      t.in = blob + next->mf; t.bn = blob + next->b; t.on = nout; t.nn = next->nout; t.nos = nos; t.nvalid = nvalid;
       if (rotary) { t.cs = CS; t.hd = hd; t.rot_cols = 2 * d; }
     }
     LG_CHECK(launch_lg_tail(t, st), what);
@@ -340,7 +372,15 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     {
       LgLinArgs a = linear(L.qkv, X, d, d, nullptr, 0, 0, T3, 3 * d, R, 3 * d, LG_EPI_ROTARY);
       a.cs = CS; a.hd = hd; a.rot_cols = 2 * d;
-      if (!(fused && i > 0)) LG_CHECK(launch_lg_linear(a, st), "self_attn.Wqkv");      // (i > 0: done by the previous tail)
+      if (fused && i == 0) {           // the tail kernel's projection-only mode: same arithmetic as every later Wqkv
+        LgTailArgs t{};
+        t.x = X; t.rows = R; t.D = d;
+        t.in = blob + L.qkv.mf; t.bn = blob + L.qkv.b; t.on = T3; t.nn = L.qkv.nout; t.nos = 3 * d; t.nvalid = 3 * d;
+        t.cs = CS; t.hd = hd; t.rot_cols = 2 * d;
+        LG_CHECK(launch_lg_tail(t, st), "self_attn.Wqkv");
+      } else if (!fused) {             // (fused, i > 0: done by the previous tail)
+        LG_CHECK(launch_lg_linear(a, st), "self_attn.Wqkv");
+      }
       if (M == N) {   // both images as one batch of 2B sequences
         AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
         t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d; t.prec = 1;
