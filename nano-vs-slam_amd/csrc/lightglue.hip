@@ -451,10 +451,28 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   const int tid = threadIdx.x, D = a.D, M = a.M, N = a.N;
   const float* f0 = a.fz + (size_t)b * M * a.fs;
   const float* f1 = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs;
-  for (int e = tid; e < 64 * D; e += 256) {
-    const int r = e / D, k = e - r * D;
-    at[k * 64 + r] = i0 + r < M ? f0[(size_t)(i0 + r) * a.fs + k] : 0.f;
-    bt[k * 64 + r] = j0 + r < N ? f1[(size_t)(j0 + r) * a.fs + k] : 0.f;
+  // (a run-time-bounded loop with the loads inside is not unrolled: its round trips to L2 ran one after the other,
+  // and one workgroup took 10 us for 0.26 MFLOP.  All loads of a thread are issued before the first LDS write.)
+  {
+    const int q = D >> 2;                    // 16-byte granules per row (D = 32 or 64: 2 or 4 per thread and matrix)
+    float4 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u, r = e / q, k = 4 * (e - r * q);
+      va[u] = vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 64 * q) {
+        if (i0 + r < M) va[u] = *reinterpret_cast<const float4*>(f0 + (size_t)(i0 + r) * a.fs + k);
+        if (j0 + r < N) vb[u] = *reinterpret_cast<const float4*>(f1 + (size_t)(j0 + r) * a.fs + k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u, r = e / q, k = 4 * (e - r * q);
+      if (e < 64 * q) {
+        at[k * 64 + r] = va[u].x; at[(k + 1) * 64 + r] = va[u].y; at[(k + 2) * 64 + r] = va[u].z; at[(k + 3) * 64 + r] = va[u].w;
+        bt[k * 64 + r] = vb[u].x; bt[(k + 1) * 64 + r] = vb[u].y; bt[(k + 2) * 64 + r] = vb[u].z; bt[(k + 3) * 64 + r] = vb[u].w;
+      }
+    }
   }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
@@ -548,6 +566,40 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   }
 }
 
+// merge n per-tile partials (stride apart) in tile order; sixteen pairs of loads in flight at a time
+__device__ __forceinline__ void lse_merge_partials(const float* pm, const float* ps, int n, size_t stride, float& m, float& s) {
+  m = -INFINITY; s = 0.f;
+  for (int t0 = 0; t0 < n; t0 += 16) {
+    float vm[16], vs[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      vm[u] = -INFINITY; vs[u] = 0.f;
+      if (t0 + u < n) { vm[u] = pm[(size_t)(t0 + u) * stride]; vs[u] = ps[(size_t)(t0 + u) * stride]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (t0 + u < n) lse_merge(m, s, vm[u], vs[u]);
+  }
+}
+// max / argmax over n per-tile partials in tile order (strict >: the lowest tile wins ties)
+__device__ __forceinline__ int best_of_partials(const float* pm, const int* pa, int n, size_t stride, float& mx) {
+  mx = -INFINITY;
+  int arg = 0;
+  for (int t0 = 0; t0 < n; t0 += 16) {
+    float vm[16];
+    int va[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      vm[u] = -INFINITY; va[u] = 0;
+      if (t0 + u < n) { vm[u] = pm[(size_t)(t0 + u) * stride]; va[u] = pa[(size_t)(t0 + u) * stride]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (vm[u] > mx) { mx = vm[u]; arg = va[u]; }
+  }
+  return arg;
+}
+
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 
 // one 64 x 64 tile of scores: inner block <- log_softmax rows + log_softmax cols + certainties
@@ -563,15 +615,23 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
   const float* z0p = a.fz + (size_t)b * M * a.fs + a.D;                          // matchability logits of image 0
   const float* z1p = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs + a.D;      // ... of image 1
+  // sim tile in: whole 64-float row segments per wave load (see lg_sim_kernel), all sixteen issued before anything
+  // waits — the merges below then run under their latency
+  float tin[16];
+  {
+    const int j = j0 + (tid & 63), w = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + 16 * w + r;
+      tin[r] = (i < M && j < N) ? sc[(size_t)i * (N + 1) + j] : 0.f;
+    }
+  }
   if (tid < 64) {
     const int i = i0 + tid;
     float base = 0.f;
     if (i < M) {
-      float m = -INFINITY, s = 0.f;
-      for (int t = 0; t < TN; ++t) {
-        const size_t e = ((size_t)b * TN + t) * M + i;
-        lse_merge(m, s, a.rp_m[e], a.rp_s[e]);
-      }
+      float m, s;
+      lse_merge_partials(a.rp_m + (size_t)b * TN * M + i, a.rp_s + (size_t)b * TN * M + i, TN, M, m, s);
       const float z0 = z0p[(size_t)i * a.fs];
       base = log_sigmoid(z0) - (m + logf(s));
       if (blockIdx.x == 0) sc[(size_t)i * (N + 1) + N] = log_sigmoid(-z0);
@@ -581,11 +641,8 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
     const int c = tid - 64, j = j0 + c;
     float cl = 0.f, ls1 = 0.f;
     if (j < N) {
-      float m = -INFINITY, s = 0.f;
-      for (int t = 0; t < TM; ++t) {
-        const size_t e = ((size_t)b * TM + t) * N + j;
-        lse_merge(m, s, a.cp_m[e], a.cp_s[e]);
-      }
+      float m, s;
+      lse_merge_partials(a.cp_m + (size_t)b * TM * N + j, a.cp_s + (size_t)b * TM * N + j, TM, N, m, s);
       cl = m + logf(s);
       const float z1 = z1p[(size_t)j * a.fs];
       ls1 = log_sigmoid(z1);
@@ -595,14 +652,8 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   } else if (tid == 128 && blockIdx.x == 0 && blockIdx.y == 0) {
     sc[(size_t)M * (N + 1) + N] = 0.f;
   }
-  {   // sim tile in: whole 64-float row segments per wave load (see lg_sim_kernel)
-    const int j = j0 + (tid & 63), w = tid >> 6;
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + 16 * w + r;
-      tile[(16 * w + r) * LG_TP + (tid & 63)] = (i < M && j < N) ? sc[(size_t)i * (N + 1) + j] : 0.f;
-    }
-  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[(16 * (tid >> 6) + r) * LG_TP + (tid & 63)] = tin[r];
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
   float v[4][4];
@@ -661,7 +712,7 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   __syncthreads();
   {   // final tile out
     const int j = j0 + (tid & 63);
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = i0 + 16 * wave + r;
       if (i < M && j < N) sc[(size_t)i * (N + 1) + j] = tile[(16 * wave + r) * LG_TP + (tid & 63)];
@@ -683,24 +734,11 @@ __global__ __launch_bounds__(256) void lg_filter_kernel(const LgAssignArgs a) {
   const int TN = (N + 63) >> 6, TM = (M + 63) >> 6;
   const int e = blockIdx.x * 256 + threadIdx.x;
   auto row_best = [&](int i, float& mx) {
-    mx = -INFINITY;
-    int arg = 0;
-    for (int t = 0; t < TN; ++t) {
-      const size_t k = ((size_t)b * TN + t) * M + i;
-      const float v = a.rmax[k];
-      if (v > mx) { mx = v; arg = a.rarg[k]; }
-    }
-    return arg;
+    return best_of_partials(a.rmax + (size_t)b * TN * M + i, a.rarg + (size_t)b * TN * M + i, TN, M, mx);
   };
   auto col_best = [&](int j) {
-    float mx = -INFINITY;
-    int arg = 0;
-    for (int t = 0; t < TM; ++t) {
-      const size_t k = ((size_t)b * TM + t) * N + j;
-      const float v = a.cmax[k];
-      if (v > mx) { mx = v; arg = a.carg[k]; }
-    }
-    return arg;
+    float mx;
+    return best_of_partials(a.cmax + (size_t)b * TM * N + j, a.carg + (size_t)b * TM * N + j, TM, N, mx);
   };
   if (e < M) {
     float mx;
