@@ -190,7 +190,7 @@ int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s) {
 //   a cap above 16384 on a big frame): survivors are compacted into the caller's idx row and sorted IN PLACE in
 //   global memory, keys rebuilt from score[idx] — no scratch buffer in the ABI, any k up to n.
 // ---------------------------------------------------------------------------------------------
-constexpr int TOPK_SMALL_MAX = 512;      // 256-thread workgroups up to here (1024 threads beyond: k = 1000 at 64 frames 3.07 -> 3.06 ms/step)
+constexpr int TOPK_SMALL_MAX = 256;      // 256-thread workgroups up to here; beyond, 1024 threads hold one key each in the sort
 constexpr int TOPK_LDS_MAX = 16384;      // keys that fit the LDS path
 
 __device__ __forceinline__ unsigned long long topk_key(float s, int idx, float thr) {
@@ -203,9 +203,13 @@ __device__ __forceinline__ unsigned long long topk_key(float s, int idx, float t
 // Shared front half: count the candidates and, when there are more than k of them, find the k-th largest key.
 // hist: LDS [260] (256 bins + rank, ncand, fill, done); s_prefix: LDS.  Returns the selection threshold
 // (1: every candidate, ~0: nothing) and the number of selected keys through `count_out`.
+// kreg / cached: the thread's keys (element tid + u NTHR) already in registers — the frame is then read from memory
+// once, all loads in flight together, instead of once per pass in a loop whose round trips run one after another
+constexpr int TOPK_KPT = 8;
 template <int NTHR>
 __device__ __forceinline__ unsigned long long topk_threshold(const float* sc, int n, int k, float thr, unsigned* hist,
-                                                             unsigned long long& s_prefix, unsigned& count_out) {
+                                                             unsigned long long& s_prefix, unsigned& count_out,
+                                                             const unsigned long long (&kreg)[TOPK_KPT], bool cached) {
   const int tid = threadIdx.x;
   unsigned& s_rank = hist[256];
   unsigned& s_ncand = hist[257];
@@ -213,7 +217,12 @@ __device__ __forceinline__ unsigned long long topk_threshold(const float* sc, in
   if (tid == 0) s_ncand = 0;
   __syncthreads();
   unsigned local = 0;
-  for (int e = tid; e < n; e += NTHR) local += (sc[e] > thr) ? 1u : 0u;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < TOPK_KPT; ++u) local += kreg[u] != 0ull ? 1u : 0u;
+  } else {
+    for (int e = tid; e < n; e += NTHR) local += (sc[e] > thr) ? 1u : 0u;
+  }
   atomicAdd(&s_ncand, local);
   __syncthreads();
   const unsigned ncand = s_ncand;
@@ -229,9 +238,17 @@ __device__ __forceinline__ unsigned long long topk_threshold(const float* sc, in
     const unsigned long long prefix = s_prefix;
     const int shift = pass * 8;
     const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
-    for (int e = tid; e < n; e += NTHR) {
-      const unsigned long long key = topk_key(sc[e], e, thr);
-      if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < TOPK_KPT; ++u) {
+        const unsigned long long key = kreg[u];
+        if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
+    } else {
+      for (int e = tid; e < n; e += NTHR) {
+        const unsigned long long key = topk_key(sc[e], e, thr);
+        if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -268,41 +285,89 @@ __device__ __forceinline__ unsigned long long topk_threshold(const float* sc, in
 
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void topk_kernel(const TopkArgs a, const int kpow) {
-  // all LDS in the dynamic region (16-byte aligned base): [kpow] keys | prefix | (pad) | hist[256] | 4 counters
+  // all LDS in the dynamic region (16-byte aligned base): [kpow] keys | prefix | (pad) | hist[256] | 4 counters | [NTHR] keys
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
   const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
   const float* sc = a.score + (size_t)b * n;
   unsigned long long& s_prefix = s_keys[kpow];
   unsigned* hist = reinterpret_cast<unsigned*>(&s_keys[kpow + 2]);
   unsigned& s_fill = hist[258];
+  unsigned long long* s_keys2 = &s_keys[kpow + 2 + 130];      // [NTHR], the register sort's second exchange buffer
 
   // kpow >= 2 always (launch_topk): the sort's first compare reads s_keys[0] and s_keys[1], both inside the key region
   for (int e = tid; e < kpow; e += NTHR) s_keys[e] = 0ull;
+  const bool cached = n <= TOPK_KPT * NTHR;
+  unsigned long long kreg[TOPK_KPT];
+#pragma unroll
+  for (int u = 0; u < TOPK_KPT; ++u) {
+    const int e = tid + u * NTHR;
+    kreg[u] = (cached && e < n) ? topk_key(sc[e], e, a.thr) : 0ull;
+  }
   unsigned count;
-  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count);
+  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count, kreg, cached);
   if (tid == 0) { a.count[b] = (int)count; s_fill = 0; }
   __syncthreads();
-  for (int e = tid; e < n; e += NTHR) {
-    const unsigned long long key = topk_key(sc[e], e, a.thr);
-    if (key != 0ull && key >= thresh) {
-      const unsigned slot = atomicAdd(&s_fill, 1u);
-      if (slot < (unsigned)kpow) s_keys[slot] = key;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < TOPK_KPT; ++u) {
+      const unsigned long long key = kreg[u];
+      if (key != 0ull && key >= thresh) {
+        const unsigned slot = atomicAdd(&s_fill, 1u);
+        if (slot < (unsigned)kpow) s_keys[slot] = key;
+      }
+    }
+  } else {
+    for (int e = tid; e < n; e += NTHR) {
+      const unsigned long long key = topk_key(sc[e], e, a.thr);
+      if (key != 0ull && key >= thresh) {
+        const unsigned slot = atomicAdd(&s_fill, 1u);
+        if (slot < (unsigned)kpow) s_keys[slot] = key;
+      }
     }
   }
   __syncthreads();
   // bitonic sort, descending, of the smallest power-of-two prefix that holds the selected keys (the rest are zeros)
   int ksort = 2;
   while (ksort < (int)count) ksort <<= 1;
-  for (int size = 2; size <= ksort; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (ksort >> 1); t += NTHR) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long x = s_keys[lo], y = s_keys[hi];
-        if ((x < y) == desc) { s_keys[lo] = y; s_keys[hi] = x; }
+  if (ksort <= NTHR) {
+    // One key per thread, in a register.  Compare-exchanges whose partner is in the same wave (stride < 64: 45 of the
+    // 55 steps at 1024 keys) are two lane shuffles; only the wider ones go through LDS, ping-ponging between the key
+    // array and a second buffer so that each costs ONE barrier.  (A barrier per step, 1024 threads: 14 us of the
+    // kernel's 25 at one frame.)
+    unsigned long long* buf[2] = {s_keys, s_keys2};
+    int pp = 0;
+    unsigned long long x = tid < ksort ? s_keys[tid] : 0ull;
+    for (int size = 2; size <= ksort; size <<= 1) {
+      const bool desc = (tid & size) == 0;
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        unsigned long long y;
+        if (stride >= 64) {
+          if (tid < ksort) buf[pp][tid] = x;   // (its readers of two exchanges ago have all passed the last barrier)
+          __syncthreads();
+          y = tid < ksort ? buf[pp][tid ^ stride] : 0ull;
+          pp ^= 1;
+        } else {
+          y = __shfl_xor(x, stride);
+        }
+        const bool want_max = ((tid & stride) == 0) == desc;
+        x = want_max ? (x > y ? x : y) : (x < y ? x : y);
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    if (tid < ksort) s_keys[tid] = x;
+    __syncthreads();
+  } else {
+    for (int size = 2; size <= ksort; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (ksort >> 1); t += NTHR) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long x = s_keys[lo], y = s_keys[hi];
+          if ((x < y) == desc) { s_keys[lo] = y; s_keys[hi] = x; }
+        }
+        __syncthreads();
+      }
     }
   }
   for (int e = tid; e < a.k; e += NTHR) {
@@ -327,7 +392,8 @@ __global__ __launch_bounds__(1024) void topk_global_kernel(const TopkArgs a) {
   int32_t* idx = a.idx + (size_t)b * a.k;
   unsigned& s_fill = hist[258];
   unsigned count;
-  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count);
+  const unsigned long long no_keys[TOPK_KPT] = {};
+  const unsigned long long thresh = topk_threshold<NTHR>(sc, n, a.k, a.thr, hist, s_prefix, count, no_keys, false);
   if (tid == 0) { a.count[b] = (int)count; s_fill = 0; }
   __syncthreads();
   for (int e = tid; e < n; e += NTHR) {
@@ -378,7 +444,7 @@ int launch_topk(const TopkArgs& a, hipStream_t s) {
   }
   int kpow = 2;                                 // >= 2: the sort network always touches two key slots
   while (kpow < keff) kpow <<= 1;
-  const size_t lds = (size_t)kpow * 8 + 16 + 260 * 4;
+  const size_t lds = (size_t)kpow * 8 + 16 + 260 * 4 + 1024 * 8;
   static const int small_max = getenv("KP2D_TOPK_SMALL") ? atoi(getenv("KP2D_TOPK_SMALL")) : TOPK_SMALL_MAX;
   if (keff <= small_max) {
     hipLaunchKernelGGL(topk_kernel<256>, dim3(a.B), dim3(256), lds, s, a, kpow);
