@@ -198,7 +198,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
-    from nano_vs_slam_amd.selectors import gather_keypoints, select_topk
+    from nano_vs_slam_amd.selectors import select_and_gather
     from nano_vs_slam_amd.sharding import broadcast_model_weights
 
     model = tiny_factory(args.config, args.n_classes, v3=args.v3)
@@ -237,8 +237,7 @@ def main():
     def step():
         out = model(x)
         out = model.post_processing(out, H, W)
-        idx, val, cnt = select_topk(out["score"], args.top_k, 0.7)
-        pts, desc = gather_keypoints(out["coord"], out["feat"], idx)
+        idx, val, cnt, pts, desc = select_and_gather(out["score"], out["coord"], out["feat"], args.top_k, 0.7)
         return out, pts, desc, cnt
 
     def fence():

@@ -141,6 +141,12 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
 int kp2d_gather_keypoints(const float* coord, const float* desc, const int32_t* idx, int B, int C, int n, int k,
                           float* pts, float* dsel, void* stream);
 
+/* kp2d_select_topk + kp2d_gather_keypoints as one call (still two launches): what every caller of the selectors
+ * does next (visual_odometry.py:113-117 indexes coord / feat with the selection; extractors/kp2dtiny.py:41-42 gathers
+ * keypoints and descriptors).  Same outputs, bit for bit, as the two calls. */
+int kp2d_select_keypoints(const float* score, const float* coord, const float* desc, int B, int C, int n, int k, float thr,
+                          int32_t* idx, float* val, int32_t* count, float* pts, float* dsel, void* stream);
+
 /* replaces the per-frame front-end of inference() (src/evaluation/visual_odometry.py:77-87): kornia.image_to_tensor
  * / 255, kornia bilinear resize (align_corners=False), .sub(0.5).mul(2).  frames: uint8 [B,Hs,Ws,3] on the device;
  * x: float32 [B,3,H,W]. */

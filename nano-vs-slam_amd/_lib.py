@@ -85,6 +85,7 @@ SIGNATURES = {
     "kp2d_vlad_dim": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "kp2d_select_topk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),
     "kp2d_gather_keypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "kp2d_select_keypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P]),
     "kp2d_preprocess": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "kp2d_match_descriptors": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "kp2d_set_profiling": (C.c_int, [_P, C.c_int]),

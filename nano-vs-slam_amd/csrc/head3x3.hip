@@ -23,10 +23,10 @@ constexpr int HD_IT = (HD_G + 255) / 256;
 }  // namespace
 
 // a.w: [chunk][tap][4][16] floats (kp2d_api.cpp pack(): ConvPack::wd_off), a.scale / a.shift: [cout]
+// LDS (dynamic): s_in [HD_HY * HD_ROW] floats (30,720 B), then s_part [4 * CO * 64]
 template <int CO>
-__global__ __launch_bounds__(256) void head3x3_kernel(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_in[HD_HY * HD_ROW];             // 30,720 B
-  __shared__ float s_part[4 * CO * 64];
+__device__ __forceinline__ void head3x3_body(const ConvArgs& a, float* const s_in) {
+  float* const s_part = s_in + HD_HY * HD_ROW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
@@ -109,20 +109,53 @@ __global__ __launch_bounds__(256) void head3x3_kernel(const ConvArgs a) {
   }
 }
 
-int launch_head3x3(const ConvArgs& a0, hipStream_t s) {
+template <int CO>
+__global__ __launch_bounds__(256) void head3x3_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+  head3x3_body<CO>(a, hd_smem);
+}
+
+// KP2DTinyV2's score head (64 -> 1, sigmoid) and location head (64 -> 2, tanh) on the same grid in ONE launch
+// (blockIdx.y picks the head): at a single frame a launch costs >= 4.3 us whatever it computes.
+__global__ __launch_bounds__(256) void head3x3_pair_kernel(const ConvArgs a0, const ConvArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+  if (blockIdx.y == 0) head3x3_body<1>(a0, hd_smem);
+  else head3x3_body<2>(a1, hd_smem);
+}
+
+static int head3x3_check(const ConvArgs& a0) {
   if (a0.taps != 9 || a0.cout < 1 || a0.cout > 4 || a0.store != ST_NCHW || a0.in1.c != 0 || a0.act == ACT_SOFTMAX_C) return -1000;
   if (a0.in0.rs != (long)a0.W * a0.in0.ps) return -1004;
   if ((long)a0.H * a0.W * a0.in0.ps * 4 >= 0x7ffffff0L) return -1002;
+  return 0;
+}
+static size_t head3x3_lds(int co) { return (size_t)(HD_HY * HD_ROW + 4 * co * 64) * sizeof(float); }
+
+int launch_head3x3(const ConvArgs& a0, hipStream_t s) {
+  if (int e = head3x3_check(a0)) return e;
   ConvArgs a = a0;
   a.tiles_x = (a.W + HD_TX - 1) / HD_TX;
   a.tiles_y = (a.H + HD_TY - 1) / HD_TY;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B);
+  const size_t lds = head3x3_lds(a.cout);
   switch (a.cout) {
-    case 1: hipLaunchKernelGGL((head3x3_kernel<1>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((head3x3_kernel<2>), grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((head3x3_kernel<3>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((head3x3_kernel<4>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((head3x3_kernel<1>), grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((head3x3_kernel<2>), grid, dim3(256), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((head3x3_kernel<3>), grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL((head3x3_kernel<4>), grid, dim3(256), lds, s, a); break;
   }
+  return (int)hipGetLastError();
+}
+
+// a0: one output channel, a1: two; same map size and batch
+int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
+  if (int e = head3x3_check(a0)) return e;
+  if (int e = head3x3_check(a1)) return e;
+  if (a0.cout != 1 || a1.cout != 2 || a0.H != a1.H || a0.W != a1.W || a0.B != a1.B) return -1005;
+  ConvArgs x = a0, y = a1;
+  x.tiles_x = y.tiles_x = (x.W + HD_TX - 1) / HD_TX;
+  x.tiles_y = y.tiles_y = (x.H + HD_TY - 1) / HD_TY;
+  hipLaunchKernelGGL(head3x3_pair_kernel, dim3(x.tiles_x * x.tiles_y * x.B, 2), dim3(256), head3x3_lds(2), s, x, y);
   return (int)hipGetLastError();
 }
 

@@ -628,12 +628,11 @@ struct Plan {
     s.ps = ps; s.rs = (long)t.W * ps; s.bs = (long)t.H * t.W * ps;
     return s;
   }
-  // core launch: sources already described
-  void conv_src(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
-                int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
-    if (rc != KP2D_OK || dry) return;
+  // arguments of one conv launch; false (rc set) when the plan and the layer disagree
+  bool conv_args(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
+                 int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc, ConvArgs& a) {
     const ConvPack& c = m->convs[m->conv_index.at(name)];
-    ConvArgs a{};
+    a = ConvArgs{};
     a.in0 = s0; a.in1 = s1; a.taps = c.taps;
     const bool split = m->precision == KP2D_PREC_F16X3;
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
@@ -652,13 +651,29 @@ struct Plan {
     a.out0 = out0; a.os0 = os0; a.oo0 = oo0; a.out1 = out1; a.os1 = os1; a.oo1 = oo1;
     a.B = B; a.H = Hc; a.W = Wc; a.cin = c.cin; a.cout = c.cout; a.npad = c.npad;
     a.act = act; a.store = store; a.nsplit = nsplit;
-    if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return; }
+    if (s0.c + s1.c != c.cin) { rc = fail(KP2D_ERR_ARG, "%s: plan feeds %d channels, layer expects %d", name.c_str(), s0.c + s1.c, c.cin); return false; }
+    return true;
+  }
+  // score / loc / depth heads: 1-4 output channels as an HBM-bound dot-product kernel (exact fp32 in both modes)
+  bool head_dot(const ConvPack& c, const ConvArgs& a) const {
+    return c.head() && a.store == ST_NCHW && a.in1.c == 0 && a.act != ACT_SOFTMAX_C && m->head_dot;
+  }
+  void head_dot_args(const ConvPack& c, ConvArgs& a) const {
+    a.prec = 0;
+    a.w = m->blob + c.wd_off;
+    a.scale = m->blob + c.sc_off;
+  }
+  // core launch: sources already described
+  void conv_src(const std::string& name, const ConvSrc& s0, const ConvSrc& s1, int act, int store, float* out0, int os0,
+                int oo0, float* out1, int os1, int oo1, int nsplit, int Hc, int Wc) {
+    if (rc != KP2D_OK || dry) return;
+    const ConvPack& c = m->convs[m->conv_index.at(name)];
+    ConvArgs a;
+    if (!conv_args(name, s0, s1, act, store, out0, os0, oo0, out1, os1, oo1, nsplit, Hc, Wc, a)) return;
+    const bool split = m->precision == KP2D_PREC_F16X3;
     const double px = (double)B * Hc * Wc;
-    if (c.head() && store == ST_NCHW && s1.c == 0 && act != ACT_SOFTMAX_C && m->head_dot) {
-      // score / loc / depth heads: 1-4 output channels as an HBM-bound dot-product kernel (exact fp32 in both modes)
-      a.prec = 0;
-      a.w = m->blob + c.wd_off;
-      a.scale = m->blob + c.sc_off;
+    if (head_dot(c, a)) {
+      head_dot_args(c, a);
       prof_begin(name, "conv3x3_head", 2.0 * 9 * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * 9 * c.cin * c.cout);
       check(launch_head3x3(a, stream), name.c_str());
       prof_end();
@@ -669,6 +684,30 @@ struct Plan {
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
     check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
     prof_end();
+  }
+  // KP2DTinyV2's score head (-> 1 channel, sigmoid) and location head (-> 2, tanh): planar outputs, one launch for both
+  // when both run as dot-product kernels (per-layer profiling keeps them apart)
+  void head_pair(const std::string& n0, const Act& in0, int act0, float* out0, const std::string& n1, const Act& in1, int act1,
+                 float* out1, int Hc, int Wc) {
+    if (rc != KP2D_OK || dry) return;
+    const ConvPack& c0 = m->convs[m->conv_index.at(n0)];
+    const ConvPack& c1 = m->convs[m->conv_index.at(n1)];
+    ConvArgs a0, a1;
+    const ConvSrc none0 = dense(ptr(in0), in0, 0, 0), none1 = dense(ptr(in1), in1, 0, 0);
+    if (!conv_args(n0, dense(ptr(in0), in0, in0.C, 0), none0, act0, ST_NCHW, out0, 0, 0, nullptr, 0, 0, c0.cout, Hc, Wc, a0)) return;
+    if (!conv_args(n1, dense(ptr(in1), in1, in1.C, 0), none1, act1, ST_NCHW, out1, 0, 0, nullptr, 0, 0, c1.cout, Hc, Wc, a1)) return;
+    // few frames only: at 64 frames the two launches overlap their tails and the pair is 0.4 % of the step slower
+    // (21.16k vs 21.24k frames/s, three alternating runs); at one frame it saves a 4-us launch (0.273 -> 0.265 ms)
+    static const bool pair_env = !(getenv("KP2D_HEAD_PAIR") && getenv("KP2D_HEAD_PAIR")[0] == '0');      // (A/B knob)
+    const bool pair_on = pair_env && (long)((Wc + 15) / 16) * ((Hc + 3) / 4) * B < 1024;
+    if (!pair_on || m->profiling || !head_dot(c0, a0) || !head_dot(c1, a1) || c0.cout != 1 || c1.cout != 2) {
+      conv(n0, in0, in0.C, 0, nullptr, act0, ST_NCHW, out0, 0, 0, nullptr, 0, 0, c0.cout, Hc, Wc);
+      conv(n1, in1, in1.C, 0, nullptr, act1, ST_NCHW, out1, 0, 0, nullptr, 0, 0, c1.cout, Hc, Wc);
+      return;
+    }
+    head_dot_args(c0, a0);
+    head_dot_args(c1, a1);
+    check(launch_head3x3_pair(a0, a1, stream), n0.c_str());
   }
   // generic conv over dense NHWC activations: in1 may be null (no concat).  Channel slices via (c0, o0).
   void conv(const std::string& name, const Act& in0, int c0, int o0, const Act* in1, int act, int store,
@@ -856,10 +895,9 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(s1);
   } else {
     Act s1 = first("score_head.convDa");
-    P.conv("score_head.convDb", s1, s1.C, 0, nullptr, ACT_SIGMOID, ST_NCHW, o.score, 0, 0, nullptr, 0, 0, 1, Hc, Wc);
-    P.release(s1);
     Act l1 = first("loc_head.convDa");
-    P.conv("loc_head.convDb", l1, l1.C, 0, nullptr, ACT_TANH, ST_NCHW, o.shift, 0, 0, nullptr, 0, 0, 2, Hc, Wc);
+    P.head_pair("score_head.convDb", s1, ACT_SIGMOID, o.score, "loc_head.convDb", l1, ACT_TANH, o.shift, Hc, Wc);
+    P.release(s1);
     P.release(l1);
     // ---- descriptor head (heads.py:91-104) ----
     Act d1 = first("desc_head.convA");
@@ -1297,6 +1335,12 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
   a.cell = 1 << m->cfg.downsample;
   a.cross_ratio = 2.0f;   // kp2dtiny.py:339
   if (!desc) a.C = 32;
+  if (seg_ids && !sample_segmentation) {        // the dense argmax does not depend on the decoded coordinates: one launch
+    const ArgmaxArgs g{seg, seg_ids, B, seg_c, Hs * Ws};
+    const int e = launch_post_seg(a, g, (hipStream_t)stream);
+    if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "post / argmax kernel: %d (descriptor channels %d)", e, feat_c);
+    return KP2D_OK;
+  }
   int e = launch_post(a, (hipStream_t)stream);
   if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "post kernel: %d (descriptor channels %d)", e, feat_c);
   if (seg_ids && sample_segmentation) {
@@ -1320,6 +1364,24 @@ int kp2d_select_topk(const float* score, int B, int n, int k, float thr, int32_t
   TopkArgs a{score, B, n, k, thr, idx, val, count};
   int e = launch_topk(a, (hipStream_t)stream);
   if (e) return fail(KP2D_ERR_HIP, "topk kernel: %d", e);
+  return KP2D_OK;
+}
+
+int kp2d_select_keypoints(const float* score, const float* coord, const float* desc, int B, int C, int n, int k, float thr,
+                          int32_t* idx, float* val, int32_t* count, float* pts, float* dsel, void* stream) {
+  if (!score || !coord || !desc || !idx || !count || !pts || !dsel) return fail(KP2D_ERR_ARG, "null argument");
+  if (B < 1 || n < 1 || C < 1) return fail(KP2D_ERR_ARG, "empty score map (B=%d, n=%d, C=%d)", B, n, C);
+  if (k < 1) return fail(KP2D_ERR_ARG, "k must be >= 1 (pass k = n for \"every cell above the threshold\")");
+  DeviceGuard guard(score, (hipStream_t)stream);
+  // Two launches.  (The gather inside the top-k kernel — the sorted keys are still in LDS — was built and measured: one
+  // workgroup per frame fetching k * C scattered values is 20 us slower at a single frame than the 250 workgroups of
+  // the gather kernel, 0.276 -> 0.295 ms per frame.)
+  const TopkArgs a{score, B, n, k, thr, idx, val, count};
+  int e = launch_topk(a, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "topk kernel: %d", e);
+  const GatherArgs g{coord, desc, idx, pts, dsel, B, C, n, k};
+  e = launch_gather(g, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "gather kernel: %d", e);
   return KP2D_OK;
 }
 

@@ -59,6 +59,7 @@ struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC 
 int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s);
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, int Ws, hipStream_t s);   // frame front-end fused in
+int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s);   // a 1-channel and a 2-channel head, one launch
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 
@@ -94,6 +95,7 @@ int launch_post(const PostArgs& a, hipStream_t s);
 
 struct ArgmaxArgs { const float* seg; int64_t* ids; int B, C, HW; };
 int launch_seg_argmax(const ArgmaxArgs& a, hipStream_t s);
+int launch_post_seg(const PostArgs& a, const ArgmaxArgs& g, hipStream_t s);      // both in one launch when shapes allow
 struct SegSampleArgs { const float* seg; const float* coord; int64_t* ids; int B, C, Hs, Ws, Hc, Wc, H, W; };
 int launch_seg_sample_argmax(const SegSampleArgs& a, hipStream_t s);
 

@@ -21,16 +21,15 @@ namespace kp2d {
 // wave-load still walks one feature plane), the squared norms meet in LDS.  8 gathers x 4 corners per thread instead
 // of 32 x 4 keeps four times as many loads in flight per cell.
 template <int C>
-__global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
+__device__ __forceinline__ void post_body(const PostArgs& a, const int bx, const int b) {
   __shared__ float s_ss[4][64];
   constexpr int CW = C / 4;
   const int Hc = a.Hc, Wc = a.Wc;
   const int ncell = Hc * Wc;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int b = blockIdx.y;
   // lanes past the last cell of a partial block recompute the last cell and store nothing: one control path, one barrier
-  const bool live = blockIdx.x * 64 + lane < ncell;
-  const int cell_id = live ? blockIdx.x * 64 + lane : ncell - 1;
+  const bool live = bx * 64 + lane < ncell;
+  const int cell_id = live ? bx * 64 + lane : ncell - 1;
   const int yc = cell_id / Wc, xc = cell_id - yc * Wc;
   const size_t so = (size_t)b * ncell + cell_id;
 
@@ -95,6 +94,9 @@ __global__ __launch_bounds__(256) void post_kernel(const PostArgs a) {
   }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void post_kernel(const PostArgs a) { post_body<C>(a, blockIdx.x, blockIdx.y); }
+
 int launch_post(const PostArgs& a, hipStream_t s) {
   const int ncell = a.Hc * a.Wc;
   dim3 grid((ncell + 63) / 64, a.B);
@@ -122,9 +124,8 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(const ArgmaxArgs a) {
 }
 
 // four consecutive pixels per thread (HW % 4 == 0): 16-byte loads per class plane, two 16-byte stores of ids
-__global__ __launch_bounds__(256) void seg_argmax4_kernel(const ArgmaxArgs a) {
-  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;       // quad of pixels
-  const int b = blockIdx.y;
+__device__ __forceinline__ void seg_argmax4_body(const ArgmaxArgs& a, const int bx, const int b) {
+  const size_t q = (size_t)bx * 256 + threadIdx.x;       // quad of pixels
   if (q * 4 >= (size_t)a.HW) return;
   const float4* sp = reinterpret_cast<const float4*>(a.seg + (size_t)b * a.C * a.HW) + q;
   const size_t plane4 = (size_t)a.HW >> 2;
@@ -141,6 +142,32 @@ __global__ __launch_bounds__(256) void seg_argmax4_kernel(const ArgmaxArgs a) {
   longlong2* o = reinterpret_cast<longlong2*>(a.ids + (size_t)b * a.HW + q * 4);
   o[0] = make_longlong2(b0, b1);
   o[1] = make_longlong2(b2, b3);
+}
+
+__global__ __launch_bounds__(256) void seg_argmax4_kernel(const ArgmaxArgs a) { seg_argmax4_body(a, blockIdx.x, blockIdx.y); }
+
+// post_processing's two independent halves in ONE launch: blocks [0, npost) are post_kernel's, the rest the dense class
+// argmax.  At a single frame every launch costs >= 4.3 us whatever it does (profiles/r3_ab_deep_prefetch.txt).
+template <int C>
+__global__ __launch_bounds__(256) void post_seg_kernel(const PostArgs a, const ArgmaxArgs g, const int npost) {
+  if ((int)blockIdx.x < npost) post_body<C>(a, blockIdx.x, blockIdx.y);
+  else seg_argmax4_body(g, blockIdx.x - npost, blockIdx.y);
+}
+
+int launch_post_seg(const PostArgs& a, const ArgmaxArgs& g, hipStream_t s) {
+  const bool quad = (g.HW & 3) == 0 && ((uintptr_t)g.seg & 15) == 0 && ((uintptr_t)g.ids & 15) == 0;
+  if (!quad || g.B != a.B || (a.C != 32 && a.C != 64 && a.C != 128)) {
+    if (int e = launch_post(a, s)) return e;
+    return launch_seg_argmax(g, s);
+  }
+  const int npost = (a.Hc * a.Wc + 63) / 64, nseg = (g.HW / 4 + 255) / 256;
+  const dim3 grid(npost + nseg, a.B);
+  switch (a.C) {
+    case 32: hipLaunchKernelGGL(post_seg_kernel<32>, grid, dim3(256), 0, s, a, g, npost); break;
+    case 64: hipLaunchKernelGGL(post_seg_kernel<64>, grid, dim3(256), 0, s, a, g, npost); break;
+    default: hipLaunchKernelGGL(post_seg_kernel<128>, grid, dim3(256), 0, s, a, g, npost); break;
+  }
+  return (int)hipGetLastError();
 }
 
 // sample_seg with sample_segmentation=True (models/kp2dtiny.py:634-639): nearest-neighbour grid_sample of the

@@ -178,9 +178,9 @@ class FrameStream:
                                            self.H, self.W, C.c_void_p(stream)))
             fwd = self.net(x)
         out = self.net.post_processing(fwd, self.H, self.W)
-        from .selectors import _cap, gather_keypoints, select_topk
-        idx, _val, cnt = select_topk(out["score"], _cap(self.top_k, out["score"]), self.thr)
-        pts, dsel = gather_keypoints(out["coord"], out["feat"], idx)
+        from .selectors import _cap, select_and_gather
+        idx, _val, cnt, pts, dsel = select_and_gather(out["score"], out["coord"], out["feat"], _cap(self.top_k, out["score"]),
+                                                      self.thr)
         if self.scale is not None:
             pts = pts / self.scale
         return out, pts, dsel, cnt

@@ -57,6 +57,33 @@ def gather_keypoints(coord: torch.Tensor, desc: torch.Tensor, idx: torch.Tensor)
     return pts, dsel
 
 
+def select_and_gather(score: torch.Tensor, coord: torch.Tensor, desc: torch.Tensor, k: int, thr: float = float("-inf")):
+    """``select_topk`` + ``gather_keypoints`` as one library call (bit-identical results; one trip through ctypes).
+
+    Returns (idx [B,k], val [B,k], count [B], pts [B,k,2], descriptors [B,k,C])."""
+    if score.device.type != "cuda":
+        raise RuntimeError("select_and_gather runs on the HIP device only")
+    lib = _lib.load()
+    B, Cd = desc.shape[0], desc.shape[1]
+    s = score.reshape(B, -1).contiguous().float()
+    n = s.shape[1]
+    if n != desc.shape[2] * desc.shape[3]:
+        raise ValueError("score and descriptor grids differ")
+    if k < 1:
+        raise ValueError("k must be >= 1 (use k = number of cells for 'every cell above the threshold')")
+    k = int(min(k, n))
+    coord, desc = coord.contiguous(), desc.contiguous()
+    idx = torch.empty(B, k, dtype=torch.int32, device=s.device)
+    val = torch.empty(B, k, dtype=torch.float32, device=s.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=s.device)
+    pts = torch.empty(B, k, 2, device=s.device)
+    dsel = torch.empty(B, k, Cd, device=s.device)
+    stream = torch.cuda.current_stream(s.device).cuda_stream
+    _lib.check(lib.kp2d_select_keypoints(_ptr(s), _ptr(coord), _ptr(desc), B, Cd, n, k, float(thr), _ptr(idx), _ptr(val),
+                                         _ptr(cnt), _ptr(pts), _ptr(dsel), C.c_void_p(stream)))
+    return idx, val, cnt, pts, dsel
+
+
 def _cap(top_k: int, score: torch.Tensor) -> int:
     """The reference's cap semantics (``if len(score) > top_k and top_k > 0``): top_k <= 0 means no cap."""
     n = score[0].numel()
@@ -72,8 +99,7 @@ def select_keypoints(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, scale
     the frame (evaluation/visual_odometry.py:119-121).
     """
     score, coord, feat = out["score"], out["coord"], out["feat"]
-    idx, _val, cnt = select_topk(score, _cap(top_k, score), nn_thresh)
-    pts, dsel = gather_keypoints(coord, feat, idx)
+    idx, _val, cnt, pts, dsel = select_and_gather(score, coord, feat, _cap(top_k, score), nn_thresh)
     counts = cnt.tolist()  # the only host sync: one int per frame
     res = []
     for b, n in enumerate(counts):
@@ -89,8 +115,7 @@ def select_keypoints_host(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, 
     numpy arrays.  Three device-to-host copies for the whole batch (counts, padded points, padded descriptors) instead
     of two per frame."""
     score, coord, feat = out["score"], out["coord"], out["feat"]
-    idx, _val, cnt = select_topk(score, _cap(top_k, score), nn_thresh)
-    pts, dsel = gather_keypoints(coord, feat, idx)
+    idx, _val, cnt, pts, dsel = select_and_gather(score, coord, feat, _cap(top_k, score), nn_thresh)
     if scale is not None:
         pts = pts / torch.tensor([scale[0], scale[1]], device=pts.device, dtype=pts.dtype)
     counts = cnt.tolist()
@@ -101,6 +126,5 @@ def select_keypoints_host(out: dict, nn_thresh: float = 0.7, top_k: int = 4000, 
 
 def extract_topk(out: dict, max_num_keypoints: int = 1024):
     """K3: batched top-k without threshold -> dict like the gluefactory extractor's ``pred``."""
-    idx, val, _ = select_topk(out["score"], max_num_keypoints)
-    pts, dsel = gather_keypoints(out["coord"], out["feat"], idx)
+    idx, val, _, pts, dsel = select_and_gather(out["score"], out["coord"], out["feat"], max_num_keypoints)
     return {"keypoints": pts, "keypoint_scores": val, "descriptors": dsel, "indices": idx}

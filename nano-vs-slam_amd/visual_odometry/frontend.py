@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from ..kp2dtiny.models.kp2dtiny import tiny_factory
-from ..selectors import gather_keypoints, select_topk
+from ..selectors import select_and_gather
 
 
 class KP2DtinyFrontend(object):
@@ -65,8 +65,7 @@ class KP2DtinyFrontend(object):
             score = torch.where(banned.view_as(score), torch.full_like(score, float("-inf")), score)
         # top_k <= 0 is "no cap" in the reference (frontend.py:122): every cell above the threshold is kept
         k = self.top_k if self.top_k > 0 else score[0].numel()
-        idx, _val, cnt = select_topk(score, k, self.nn_thresh)
-        pts, dsel = gather_keypoints(out["coord"], out["feat"], idx)
+        idx, _val, cnt, pts, dsel = select_and_gather(score, out["coord"], out["feat"], k, self.nn_thresh)
         n = int(cnt[0])
         sel = idx[0, :n].long()
         seg_out = seg.view(-1)[sel] if self.apply_semantic_filer else seg.view(-1)

@@ -281,6 +281,27 @@ def test_topk_kernel_against_oracle_with_ties():
             assert np.array_equal(val[b, :len(order)], s[b][order])
 
 
+def test_select_and_gather_equals_the_two_calls():
+    """kp2d_select_keypoints against kp2d_select_topk + kp2d_gather_keypoints, bit for bit, including empty frames and
+    the padded rows."""
+    from nano_vs_slam_amd.selectors import gather_keypoints, select_and_gather, select_topk
+    rng = np.random.default_rng(11)
+    for (hc, wc), cd, k, thr in [((30, 40), 32, 1000, 0.7), ((60, 80), 32, 1024, -np.inf), ((30, 40), 64, 4000, 0.7),
+                                 ((15, 20), 128, 7, 0.5), ((120, 160), 32, 19200, 0.3), ((1, 1), 32, 1, 0.5)]:
+        n = hc * wc
+        s = rng.random((3, 1, hc, wc)).astype(np.float32)
+        s[1] = 0.0                              # a frame with nothing above a positive threshold
+        coord = rng.random((3, 2, hc, wc)).astype(np.float32) * 300
+        desc = rng.standard_normal((3, cd, hc, wc)).astype(np.float32)
+        ts, tc, td = (torch.from_numpy(v).to(DEV) for v in (s, coord, desc))
+        idx, val, cnt = select_topk(ts, k, thr)
+        pts, dsel = gather_keypoints(tc, td, idx)
+        fi, fv, fc, fp, fd = select_and_gather(ts, tc, td, k, thr)
+        assert torch.equal(fi, idx) and torch.equal(fv, val) and torch.equal(fc, cnt)
+        assert torch.equal(fp, pts) and torch.equal(fd, dsel)
+        assert fp.shape == (3, min(k, n), 2) and fd.shape == (3, min(k, n), cd)
+
+
 def test_post_processing_accepts_any_forward_dict():
     """post_processing is a separate entry point: feed tensors that did not come from forward()."""
     model, _ = product_model("S", False, 28)

@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
-from nano_vs_slam_amd.selectors import gather_keypoints, select_topk
+from nano_vs_slam_amd.selectors import select_and_gather
 from nano_vs_slam_amd.synthetic import spread_state_dict
 m = tiny_factory("S", 28)
 sd = spread_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
@@ -27,8 +27,7 @@ x = torch.rand(B, 3, 240, 320, device="cuda:0") * 2 - 1
 def fwd(): return m(x)
 def full():
     out = m.post_processing(m(x), 240, 320)
-    idx, val, cnt = select_topk(out["score"], 1000, 0.7)
-    return gather_keypoints(out["coord"], out["feat"], idx)
+    return select_and_gather(out["score"], out["coord"], out["feat"], 1000, 0.7)[3:]
 def fwd_post():
     return m.post_processing(m(x), 240, 320)
 with torch.no_grad():
