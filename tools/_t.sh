@@ -1,3 +1,4 @@
-for i in 1 2 3; do for v in 1 0; do
-echo "PAIR=$v $(KP2D_HEAD_PAIR=$v python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 --warmup 5 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])')"
-done; done
+for v in 1 0 1 0; do
+KP2D_TR=$v python3 tools/layer_profile.py --reps 5 2>/dev/null > gpurun_out/lp_tr$v.txt
+done
+paste <(awk '{print $1, $2, $3}' gpurun_out/lp_tr1.txt) <(awk '{print $3}' gpurun_out/lp_tr0.txt)
