@@ -1,3 +1,5 @@
-python3 -m pytest tests -x -q -m gpu -k "select or topk or gather or keypoint or frontend or frame_stream or two_view or lightglue" 2>&1 | tail -3 || exit 1
-python3 bench.py --batch 1 --no-cpu-baseline --no-precision-modes --steps 300 --warmup 20 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("batch1", d["value"], d["ms_per_step"])'
-for i in 1 2 3; do python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 --warmup 5 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])'; done
+python3 tools/bench_lightglue.py --steps 100 --warmup 10 2>/dev/null | tail -1 | cut -c1-330
+python3 tools/bench_lightglue.py --pairs 1 --steps 200 --warmup 20 2>/dev/null | tail -1 | cut -c1-330
+python3 tools/bench_lightglue.py --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-330
+python3 tools/bench_lightglue.py --pairs 1 --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-330
+python3 bench.py --no-cpu-baseline --no-precision-modes 2>/dev/null | tail -1 | cut -c1-200
