@@ -62,7 +62,10 @@ def check(pred, ref, conf, th):
 @pytest.mark.parametrize("name,B,M,N,th", [("S", 2, 70, 53, 0.1), ("S", 1, 300, 257, 0.0), ("F", 1, 128, 96, 0.1),
                                            ("A", 3, 17, 64, 0.1),
                                            # M == N: both images' attention runs as one launch of 2B sequences
-                                           ("S", 3, 96, 96, 0.1), ("S", 1, 200, 200, 0.0)])
+                                           ("S", 3, 96, 96, 0.1), ("S", 1, 200, 200, 0.0),
+                                           # key-split attention: several 32-key rounds per wave, ragged last wave /
+                                           # a wave without keys (T = 130), 64-row tail workgroups with a ragged last one
+                                           ("S", 1, 520, 410, 0.1), ("S", 2, 130, 641, 0.0), ("S", 1, 1024, 1024, 0.1)])
 def test_lightglue_matches_oracle(name, B, M, N, th):
     from lightglue.lightglue_configs import get_light_glue_config
     conf_in = dict(get_light_glue_config(name), filter_threshold=th)

@@ -1,5 +1,1 @@
-python3 tools/bench_lightglue.py --steps 100 --warmup 10 2>/dev/null | tail -1 | cut -c1-330
-python3 tools/bench_lightglue.py --pairs 1 --steps 200 --warmup 20 2>/dev/null | tail -1 | cut -c1-330
-python3 tools/bench_lightglue.py --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-330
-python3 tools/bench_lightglue.py --pairs 1 --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-330
-python3 bench.py --no-cpu-baseline --no-precision-modes 2>/dev/null | tail -1 | cut -c1-200
+python3 -m pytest tests/test_lightglue_gpu.py -x -q -m gpu 2>&1 | tail -4
