@@ -1032,6 +1032,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
         VladArgs a{};
         a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
         a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns; a.tps = tps;
+        a.prec = m->precision == KP2D_PREC_F16X3 ? 1 : 0;
         P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
         P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
         P.prof_end();

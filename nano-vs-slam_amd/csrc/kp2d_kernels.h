@@ -72,6 +72,7 @@ struct VladArgs {
   float* out;            // [B][K*C]
   int B, S, C, K, nsplit;
   int tps = 1;           // > 1: one workgroup per 64-pixel tile, tps tiles per slab (netvlad_tiles_per_slab); part holds nsplit*tps rows
+  int prec = 0;          // 1: the soft-assignment logits as split-fp16 products (f16x3 mode); the aggregation is exact fp32 in both
 };
 int launch_netvlad(const VladArgs& a, hipStream_t s);
 struct PoolArgs { const float* x; const float* p; float* out; int B, C, Hc, Wc; };   // GeM (p = exponent) / ConvAP pooling

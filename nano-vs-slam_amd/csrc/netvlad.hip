@@ -155,13 +155,41 @@ typedef float vf16 __attribute__((ext_vector_type(16)));
 constexpr int VP = 68;   // LDS row pitch (floats) of the [row][channel] images
 constexpr int AP = 65;   // LDS row pitch of the [pixel][cluster] assignment image
 
-template <int KT>
+typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vh2 __attribute__((ext_vector_type(2)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+constexpr int HP = 72;   // LDS row pitch (halves) of the split-fp16 [row][channel] images (144 B)
+
+// four floats -> fp16 hi halves and the fp16 of the remainders (x = hi + lo to ~2^-22; attention.hip att_split2)
+__device__ __forceinline__ void vlad_split4(const float4 v, vh4& hi, vh4& lo) {
+  const vf2 a = {v.x, v.y}, b = {v.z, v.w};
+  const vh2 ha = __builtin_convertvector(a, vh2), hb = __builtin_convertvector(b, vh2);
+  unsigned la, lb;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(ha), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(la) : "v"(ha), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v.w));
+  const vh2 l0 = __builtin_bit_cast(vh2, la), l1 = __builtin_bit_cast(vh2, lb);
+  hi = vh4{ha[0], ha[1], hb[0], hb[1]};
+  lo = vh4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// SPLIT (the f16x3 arithmetic mode): the soft-assignment logits — half of the kernel's matrix work, 32 exact-fp32 MFMAs
+// of 64 cycles per 32 x 32 block — as split-fp16 products on v_mfma_f32_32x32x16_f16 (w x = wh xh + wh xl + wl xh: twelve
+// MFMAs of 32 cycles), operands |x^| <= 1 and the soft-assign weights.  The AGGREGATION stays exact fp32 in both modes:
+// its left operand is the soft assignment itself, whose small entries (1e-6 and below on sharp assignments) lose their
+// relative accuracy in fp16 halves and dominate intra-normalised rows of rarely used clusters.
+template <int KT, bool SPLIT>
 __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int KPAD = 32 * KT;
+  constexpr int WF = SPLIT ? 0 : KPAD * VP;      // SPLIT keeps its (constant) weight operands in registers
   float* s_w = sm;                   // [KPAD][VP]   soft-assign weights, channels zero-padded to 64
-  float* s_x = s_w + KPAD * VP;      // [64][VP]     normalised descriptors of the tile
+  float* s_x = sm + WF;              // [64][VP]     normalised descriptors of the tile
   float* s_a = s_x + VT * VP;        // [64][AP]     logits, then soft assignments
+  _Float16* s_xh = reinterpret_cast<_Float16*>(s_a + VT * AP);      // SPLIT: [64][HP] hi | [64][HP] lo of the same descriptors
+  _Float16* s_xl = s_xh + VT * HP;
   const int C = a.C, K = a.K, S = a.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -173,11 +201,13 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   const int s_end = a.tps > 1 ? min(min(S, slab * per + per), s_begin + VT) : min(S, s_begin + per);
   const int CQ = C >> 2;
 
-  for (int e = tid; e < KPAD * 16; e += 256) {
-    const int k = e >> 4, q = e & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K && q < CQ) v = reinterpret_cast<const float4*>(a.wa + (size_t)k * C)[q];
-    *reinterpret_cast<float4*>(&s_w[k * VP + 4 * q]) = v;
+  if constexpr (!SPLIT) {
+    for (int e = tid; e < KPAD * 16; e += 256) {
+      const int k = e >> 4, q = e & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && q < CQ) v = reinterpret_cast<const float4*>(a.wa + (size_t)k * C)[q];
+      *reinterpret_cast<float4*>(&s_w[k * VP + 4 * q]) = v;
+    }
   }
 
   // wave -> blocks: step 1 (k-tile kt1, p-tile pt1), step 2 (k-tile kt2, c-tile ct2)
@@ -185,6 +215,25 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
   const bool has1 = pt1 < 2;
   const int kt2 = wave % KT, ct2 = wave / KT;
   const bool has2 = ct2 < 2 && ct2 * 32 < C;
+  // SPLIT: this wave's weight operand of step 1, all four k-steps, split once: lane (i, h) holds channels
+  // 16 s + 8 h .. + 7 of cluster row kt1 * 32 + i
+  vh8 wrh[4], wrl[4];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      const int k = kt1 * 32 + i, c = 16 * s + 8 * h;
+      if (has1 && k < K) {
+        if (c < C) v0 = *reinterpret_cast<const float4*>(a.wa + (size_t)k * C + c);
+        if (c + 4 < C) v1 = *reinterpret_cast<const float4*>(a.wa + (size_t)k * C + c + 4);
+      }
+      vh4 h0, l0, h1, l1;
+      vlad_split4(v0, h0, l0);
+      vlad_split4(v1, h1, l1);
+      wrh[s] = vh8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      wrl[s] = vh8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+  }
   vf16 vacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) vacc[r] = 0.f;
@@ -221,9 +270,16 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
       ss += __shfl_xor(ss, 2);
       const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4)     // channels past C are written as zeros (v stayed 0)
-        *reinterpret_cast<float4*>(&s_x[p4 * VP + 16 * q4 + 4 * j4]) =
-            make_float4(v[j4].x * inv, v[j4].y * inv, v[j4].z * inv, v[j4].w * inv);
+      for (int j4 = 0; j4 < 4; ++j4) {   // channels past C are written as zeros (v stayed 0)
+        const float4 xn = make_float4(v[j4].x * inv, v[j4].y * inv, v[j4].z * inv, v[j4].w * inv);
+        *reinterpret_cast<float4*>(&s_x[p4 * VP + 16 * q4 + 4 * j4]) = xn;
+        if constexpr (SPLIT) {
+          vh4 hi, lo;
+          vlad_split4(xn, hi, lo);
+          *reinterpret_cast<vh4*>(&s_xh[p4 * HP + 16 * q4 + 4 * j4]) = hi;
+          *reinterpret_cast<vh4*>(&s_xl[p4 * HP + 16 * q4 + 4 * j4]) = lo;
+        }
+      }
     }
     if (t0 + VT < s_end) fetch(t0 + VT);
     __syncthreads();
@@ -231,6 +287,18 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
       vf16 d;
 #pragma unroll
       for (int r = 0; r < 16; ++r) d[r] = 0.f;
+      if constexpr (SPLIT) {
+        // k-step s: lane (i, h) holds channels 16 s + 8 h .. + 7 of its weight row / pixel row
+        const int xo = (pt1 * 32 + i) * HP + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const vh8 wh = wrh[s], wl = wrl[s];
+          const vh8 xh = *reinterpret_cast<const vh8*>(&s_xh[xo + 16 * s]), xl = *reinterpret_cast<const vh8*>(&s_xl[xo + 16 * s]);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, d, 0, 0, 0);
+        }
+      } else {
       const float* wr = &s_w[(kt1 * 32 + i) * VP + 32 * h];
       const float* xr = &s_x[(pt1 * 32 + i) * VP + 32 * h];
 #pragma unroll
@@ -241,6 +309,7 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
         d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, d, 0, 0, 0);
+      }
       }
       // D[row = k][col = p]: lane holds p = i, rows (r&3) + 8(r>>2) + 4h
 #pragma unroll
@@ -439,9 +508,18 @@ int launch_netvlad(const VladArgs& a, hipStream_t s) {
   if (a.K > 64 || (a.K & 3) || (a.C & 3) || a.K * a.C > 8192 || a.K < 4) return -1100;
   if ((a.K == 32 || a.K == 64) && a.C <= 64) {
     const int kt = a.K / 32;
-    const size_t lds = (size_t)(32 * kt * VP + VT * VP + VT * AP) * sizeof(float);
-    if (kt == 2) hipLaunchKernelGGL(netvlad_partial_mfma_kernel<2>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(netvlad_partial_mfma_kernel<1>, dim3(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B), dim3(256), lds, s, a);
+    static const bool split_on = !(getenv("KP2D_VLAD_SPLIT") && getenv("KP2D_VLAD_SPLIT")[0] == '0');
+    const bool split = a.prec == 1 && split_on;
+    const dim3 grid(a.nsplit * (a.tps > 1 ? a.tps : 1), a.B);
+    if (split) {
+      const size_t lds = (size_t)(VT * VP + VT * AP + VT * HP) * sizeof(float);      // (hi | lo half images = HP floats per row)
+      if (kt == 2) hipLaunchKernelGGL((netvlad_partial_mfma_kernel<2, true>), grid, dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((netvlad_partial_mfma_kernel<1, true>), grid, dim3(256), lds, s, a);
+    } else {
+      const size_t lds = (size_t)(32 * kt * VP + VT * VP + VT * AP) * sizeof(float);
+      if (kt == 2) hipLaunchKernelGGL((netvlad_partial_mfma_kernel<2, false>), grid, dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((netvlad_partial_mfma_kernel<1, false>), grid, dim3(256), lds, s, a);
+    }
   } else {
     const size_t lds1 = (size_t)(a.K * (a.C + 1) + VT * (a.C + 1) + VT * (a.K + 1)) * sizeof(float);
     if (a.K * a.C <= 4096) {
