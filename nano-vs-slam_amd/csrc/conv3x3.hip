@@ -325,7 +325,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   constexpr int KCP = KC + 4;
   constexpr int IN_PITCH = InPitch<NT, WST>::v;
   size_t lds = (size_t)(IN_ROWS * IN_PITCH * KCP + (TAPS / WST) * NT * 32 * KCP) * sizeof(float);
-  const size_t lds_out = (size_t)NT * 32 * 257 * sizeof(float);
+  const size_t lds_out = (size_t)NT * 32 * 260 * sizeof(float);      // conv_epilogue.inc: planes of 16 x 16 + 4 floats
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   // [pixel][N] staging tile of the fp32 NHWC epilogue; half the pixel rows per round for the weight-staged 64-channel tile
   const size_t lds_tile = (size_t)16 * 16 * NT * 32 * sizeof(float) / ((WST > 1 && NT == 2) ? 2 : 1);

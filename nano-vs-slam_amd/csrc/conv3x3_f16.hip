@@ -338,7 +338,7 @@ static int launch_f(const ConvArgs& a0, hipStream_t s) {
   a.tiles_x = (a.W + TW - 1) / TW;
   a.tiles_y = (a.H + TH - 1) / TH;
   size_t lds = (size_t)f_w(NP, TH) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
-  const size_t lds_out = (size_t)N * (TH * TW + 1) * sizeof(float);
+  const size_t lds_out = (size_t)N * (TH * TW + 4) * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   const size_t lds_tile = (size_t)TH * TW * N * sizeof(float);
   if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
