@@ -39,9 +39,11 @@ constexpr int F_PXB = 32;
 // image row pitch in pixel slots for a tile 16 NP pixels wide: 20 (18 used) / 36 (34 used).  Any pitch = 4 mod 8 keeps
 // every ds_read_b128 of the pixel operand conflict-free (row stride = 32 banks mod 64; brute-forced for 20, same residue
 // for 36)
-__host__ __device__ constexpr int f_pitch(int np) { return np == 1 ? 20 : 36; }
-__host__ __device__ constexpr int f_lo(int np, int th) { return (th + 2) * f_pitch(np) * F_PXB; }   // byte offset of the lo plane
-__host__ __device__ constexpr int f_w(int np, int th) { return 2 * f_lo(np, th); }                  // weight planes behind the input planes
+__host__ __device__ constexpr int f_pitch(int tw) { return tw == 16 ? 20 : 36; }                    // by tile width (16 or 32 pixels)
+__host__ __device__ constexpr int f_lo(int tw, int th) { return (th + 2) * f_pitch(tw) * F_PXB; }   // byte offset of the lo plane
+__host__ __device__ constexpr int f_w(int tw, int th) { return 2 * f_lo(tw, th); }                  // weight planes behind the input planes
+// tile width: 16 pixels per column block; the 64-channel form with 8-row tiles is 32 wide (below)
+__host__ __device__ constexpr int tile_w(int nh, int np, int th) { return (nh == 2 && th == 8) ? 32 : TILE * np; }
 
 __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
 }  // namespace
@@ -50,14 +52,20 @@ __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ?
 // NP: 16-pixel column blocks per workgroup (NP = 2, NH = 1: waves 4-7 own columns 16-31 of a 16 x 32 pixel tile and the
 //     SAME 32 channels: the weight slab — 44 % of a 32-channel tile's staged bytes — is staged once per 512 pixels, and
 //     a CU holds 16 waves (two 512-thread workgroups of 59.5 KB) instead of 12 (three 256-thread ones of 41.5 KB)).
-// TH: tile height, 16 or 8 (NH = NP = 1 only).  TH = 8 is the single-frame form: a wave owns two pixel rows (two M-tiles,
+// TH: tile height, 16 or 8.  NH = 2, TH = 8: 8 x 32 pixel tiles (a wave owns two rows x 32 columns = the same four M-tiles)
+//     for maps whose height leaves the last 16-row tile row at most half full: 120 rows are 15 tile rows of 8 instead of
+//     7.5 of 16 (80 -> 75 workgroups per frame at 160 columns, none of them half empty).
+//     NH = NP = 1, TH = 8 is the single-frame form: a wave owns two pixel rows (two M-tiles,
 //     16 accumulators), so a layer of a 60 x 80 map is 80 workgroups of half the length instead of 40 — a frame's ~25
 //     dependent launches are each as long as ONE workgroup's serial chain.
 template <int NH, int NP, int TH>
 __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
   static_assert(NH * NP <= 2, "one workgroup is 256 or 512 threads");
-  static_assert(TH == 16 || (TH == 8 && NH == 1 && NP == 1), "short tiles exist for the 256-thread form only");
-  constexpr int F_ROWS = TH + 2, MT = TH / 4;       // halo rows; M-tiles (2 x 8 pixels) per wave
+  static_assert(TH == 16 || (TH == 8 && NP == 1), "8-row tiles: the 256-thread form (16 wide) and the 64-channel form (32 wide)");
+  constexpr int TW = tile_w(NH, NP, TH);            // tile width in pixels
+  constexpr int RW = TH / 4;                        // pixel rows per wave
+  constexpr int CB = TW / (8 * NP);                 // 8-pixel column blocks per wave
+  constexpr int F_ROWS = TH + 2, MT = (RW / 2) * CB;      // halo rows; M-tiles (2 x 8 pixels) per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   constexpr int NT = NH;                            // 32-channel blocks per workgroup (conv_epilogue.inc)
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   constexpr int THREADS = 256 * NH * NP;
   constexpr int WL = 9 * N * 32;                    // byte offset of the wl plane behind the wh plane
   constexpr int KC = 16, Q = 4;
-  constexpr int F_PITCH = f_pitch(NP), F_LO = f_lo(NP, TH), F_W = f_w(NP, TH), TW = TILE * NP;
+  constexpr int F_PITCH = f_pitch(TW), F_LO = f_lo(TW, TH), F_W = f_w(TW, TH);
   auto tap_off = [](int t) constexpr { return ((t / 3) * F_PITCH + (t % 3)) * F_PXB; };
   // NP = 2: the weight slab of a chunk (18 KB) is copied global -> LDS by buffer_load ... lds (LDS-DMA, no registers, no
   // ds_write) into one of TWO slabs, requested a chunk ahead: the 512-thread form has no registers left for a weight
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   // four rows lie wholly below the map multiplies and stores nothing (it still stages and joins every barrier).
   // H = 120 / 60 otherwise spend 6.25 % of their matrix work on padding rows.
   // (and, in a 32-pixel-wide tile that hangs over the right edge, the column block wholly beyond it)
-  const bool busy = y0 + MT * wave < H && x0 + 16 * ph < W;
+  const bool busy = y0 + RW * wave < H && x0 + 16 * ph < W;
 
   f32x4 acc[MT][NN];
 #pragma unroll
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 
   // operand read addresses (bytes from the start of LDS); M-tile, tap, N-tile and slot offsets are immediates
   const int lg = lane >> 4, lp = lane & 15;     // k-group and operand row of this lane
-  const int a0 = ((wave * MT + ((lp >> 1) & 1)) * F_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
+  const int a0 = ((wave * RW + ((lp >> 1) & 1)) * F_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
   const int a_dx = a0 + (lg >> 1) * F_PXB;               // second tap one pixel to the right
   const int a_dy = a0 + (lg >> 1) * F_PITCH * F_PXB;     // second tap one row down
   const int a_s = a0 + (lg >> 1) * F_LO;                 // single tap: k-groups 2, 3 read the lo plane
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   // NP = 2 walks only the 34 used columns of a row (2448 granules = 5 per thread; the 36-slot rows would need 6) and
   // keeps the granule's image slot beside its pixel index: st = slot << 20 | pixel (0xfffff = zero padding; the
   // launcher keeps H * W below 2^20 for this variant)
-  constexpr int IN_COLS = NP == 1 ? F_PITCH : TW + 2;
+  constexpr int IN_COLS = TW == 16 ? F_PITCH : TW + 2;
   constexpr int IN_G = F_ROWS * IN_COLS * Q;
   constexpr int IN_IT = (IN_G + THREADS - 1) / THREADS;
   constexpr int PIX_NONE = 0xfffff;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
     const int py = hp / IN_COLS, px = hp - py * IN_COLS;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
     const bool ok = gi < IN_G && px < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    if (NP == 1) st_pix[it] = ok ? gy * W + gx : -1;
+    if (TW == 16) st_pix[it] = ok ? gy * W + gx : -1;
     else st_pix[it] = ((py * F_PITCH + px) << 20) | (ok ? gy * W + gx : PIX_NONE);
   }
   const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;      // pixel strides in bytes
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
       for (int it = 0; it < IN_IT; ++it) {
         int pix = st_pix[it];
         asm volatile("" : "+v"(pix));      // keep ONE register per granule: the per-source products must not be hoisted
-        if (NP != 1) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
+        if (TW != 16) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
         const int off = pix < 0 ? OOB : pix * ps + so;
         rin[it] = __builtin_bit_cast(float4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                                    : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
       for (int it = 0; it < IN_IT; ++it) {
         int pix = st_pix[it];
         asm volatile("" : "+v"(pix));
-        if (NP != 1) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
+        if (TW != 16) pix = (pix & PIX_NONE) == PIX_NONE ? -1 : (pix & PIX_NONE);
         const bool pok = cok && pix >= 0;
         const int o0 = (pok && first) ? pix * ps0 + so : OOB;
         const int o1 = (pok && !first) ? pix * ps1 + so : OOB;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
       split2(v.x, v.y, h0, l0);
       split2(v.z, v.w, h1, l1);
       // image byte of the granule: linear in the granule index (NP = 1), or slot * 32 + 8 * (granule & 3)
-      const int lb = NP == 1 ? tid * 8 + it * THREADS * 8 : (int)((unsigned)st_pix[it] >> 20) * F_PXB + (tid & 3) * 8;
+      const int lb = TW == 16 ? tid * 8 + it * THREADS * 8 : (int)((unsigned)st_pix[it] >> 20) * F_PXB + (tid & 3) * 8;
       *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
       *reinterpret_cast<f16x4*>(sm + F_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
     }
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int mo = (2 * (m >> 1) * F_PITCH + 8 * (m & 1)) * F_PXB;
+        const int mo = (2 * (m / CB) * F_PITCH + 8 * (m % CB)) * F_PXB;
         if (single) {
           // k-groups 0, 1 carry xh, groups 2, 3 xl of the same tap: both weight halves see both operand halves
           const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 #define EPI_R 4
 #define EPI_ACC(m, n, r) acc[m][n][r]
 #define EPI_CH(n) (nh * 32 + (n) * 16 + lp)
-#define EPI_ROW(m, r) (wave * MT + 2 * ((m) >> 1) + (((r) >> 1) & 1))
-#define EPI_COL(m, r) (16 * ph + 8 * ((m) & 1) + 2 * lg + ((r) & 1))
+#define EPI_ROW(m, r) (wave * RW + 2 * ((m) / CB) + (((r) >> 1) & 1))
+#define EPI_COL(m, r) (16 * ph + 8 * ((m) % CB) + 2 * lg + ((r) & 1))
 #define EPI_TW TW
 #define EPI_TH TH
 #define EPI_MVALID(m) busy
@@ -333,11 +341,11 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 
 template <int NH, int NP, int TH = TILE>
 static int launch_f(const ConvArgs& a0, hipStream_t s) {
-  constexpr int N = NH * 32, TW = TILE * NP;
+  constexpr int N = NH * 32, TW = tile_w(NH, NP, TH);
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
   a.tiles_y = (a.H + TH - 1) / TH;
-  size_t lds = (size_t)f_w(NP, TH) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
+  size_t lds = (size_t)f_w(TW, TH) + (size_t)(NP == 2 ? 2 : 1) * 2 * 9 * N * 32;     // NP = 2: two weight slabs (LDS-DMA)
   const size_t lds_out = (size_t)N * (TH * TW + 4) * sizeof(float);
   if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
   const size_t lds_tile = (size_t)TH * TW * N * sizeof(float);
@@ -362,7 +370,13 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if ((long)a.H * a.W * (a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps) * 4 >= 0x7ffffff0L) return -1002;
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32 || a.ng32;
-  if (!one) return launch_f<2, 1>(a, s);
+  if (!one) {
+    // map heights that leave the last 16-row tile row at most half full (120 = 7.5 x 16): 8 x 32 tiles, no ragged row
+    static const bool flat_on = !(getenv("KP2D_FLAT") && getenv("KP2D_FLAT")[0] == '0');
+    const int rag = a.H & 15;
+    if (flat_on && rag >= 1 && rag <= 8 && a.W >= 32 && (long)a.H * a.W < (1L << 20)) return launch_f<2, 1, 8>(a, s);
+    return launch_f<2, 1>(a, s);
+  }
   // 32-channel layers on grids that fill the chip anyway: 16 x 32 pixel tiles (one weight slab per 512 pixels, 16 waves
   // per CU).  Small grids keep the 16 x 16 tiles (twice the workgroups, half as long: single frames).  KP2D_WIDE=0: never.
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
