@@ -93,6 +93,8 @@ def test_against_reference_golden(name, precision):
     ("N_A", True, 28, 1, 32, 48),
     ("F", False, 28, 2, 48, 80),      # TINY_F: three pools (cell 8), 64-d descriptors, 64 x 128 NetVLAD
     ("D_A", True, 19, 1, 32, 48),     # LARGE_D: 64-wide conv1a, 256-wide attention (head dim 64), 128-d descriptors
+    ("S", False, 28, 2, 80, 144),     # half-resolution maps of 40 x 72: 8 x 32 conv tiles (40 % 16 = 8) with a ragged column block
+    ("S", True, 19, 1, 208, 272),     # 104 x 136 maps: 8 x 32 tiles, 13 tile rows, ragged columns, V3 heads
 ])
 def test_against_oracle_other_shapes(config, v3, ncls, B, H, W):
     model, sd = product_model(config, v3, ncls)
@@ -501,7 +503,8 @@ def test_descriptor_matching_against_oracle():
     assert {t: q for q, t in zip(i1, i2)} == {t: q for t, (q, _) in best.items()}
 
 
-@pytest.mark.parametrize("config,v3,B,H,W", [("S", False, 2, 72, 104), ("S_A", True, 1, 40, 56), ("N", False, 3, 24, 88)])
+@pytest.mark.parametrize("config,v3,B,H,W", [("S", False, 2, 72, 104), ("S_A", True, 1, 40, 56), ("N", False, 3, 24, 88),
+                                             ("S", False, 2, 80, 144)])
 def test_no_out_of_bounds_writes(config, v3, B, H, W):
     """Call the C ABI directly with guard bands around every caller-owned buffer (outputs and workspace):
     ragged tiles, padded channel groups and the LDS-transposed NCHW stores must not touch a byte outside."""
