@@ -107,7 +107,10 @@ class FrameStream:
     One frame's step is ~60 dependent launches of a few microseconds each: enqueued one by one the host is the
     bottleneck (0.59 ms per frame).  Here the whole step — kp2d_preprocess, forward, post_processing, threshold/top-k
     selection, gather and the copies of the selected rows to pinned host memory — is captured once per slot into a HIP
-    graph over static buffers and replayed with one call; frames go through ``slots`` (default 3: 2.5k, 4.2k, 6.0k, 4.7k frames/s with 1, 2, 3, 4 slots) pinned staging buffers
+    graph over static buffers and replayed with one call; frames go through ``slots`` pinned staging buffers (default 7;
+    measured on one MI355X box, frames/s by slot count: 2: 5.1k, 3: 7.1k, 4: 5.9k, 5: 7.5k, 6: 8.5k, 7: 9.4k, 8: 7.8k, 10: 9.0k,
+    12: 8.4k — multiples of the runtime's four hardware queues pair streams badly; a frame's latency is about ``slots``
+    periods, 0.75 ms at 7 — pass ``slots=3`` for 0.42 ms at 7.1k frames/s)
     that the preprocess kernel reads in place, so the host's staging of frame n+1 and the caller's work on frame n-1's
     keypoints run while frame n computes.  Every slot has its OWN compute stream and its OWN engine workspace: one
     frame's ~60 small launches fill a tenth of the chip, so the graphs of consecutive frames run side by side on the
@@ -120,7 +123,7 @@ class FrameStream:
     ``out`` holds the slot's static device tensors: valid until ``slots`` further frames have been submitted.
     """
 
-    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=3):
+    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=7):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("the frame front-end runs on the HIP device only")

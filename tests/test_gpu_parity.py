@@ -426,12 +426,13 @@ def test_frame_stream_equals_inference_frame_by_frame(src_hw, new_size, top_k):
     from nano_vs_slam_amd.pipeline import FrameStream, inference
     model, sd = product_model("S", False, 28)
     rng = np.random.default_rng(11)
-    frames = [rng.integers(0, 256, (*src_hw, 3), dtype=np.uint8) for _ in range(7)]
+    frames = [rng.integers(0, 256, (*src_hw, 3), dtype=np.uint8) for _ in range(9)]      # more frames than slots (7)
     want = []
     for f in frames:
         pts, feat, out = inference(model, f, new_size, nn_thresh=0.5, top_k=top_k)
         want.append((pts, feat, out["score"].clone(), out["seg"].clone()))
     fs = FrameStream(model, src_hw, new_size, nn_thresh=0.5, top_k=top_k, device=DEV)
+    assert fs.slots < len(frames)
     got = []
     for pts, feat, out in fs.map(frames):
         got.append((pts, feat, out["score"].clone(), out["seg"].clone()))

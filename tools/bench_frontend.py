@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--pinned", action="store_true")
     ap.add_argument("--eager", action="store_true", help="batch 1 only: call inference() per frame instead of FrameStream")
-    ap.add_argument("--slots", type=int, default=3, help="batch 1 only: FrameStream slots (frames in flight)")
+    ap.add_argument("--slots", type=int, default=7, help="batch 1 only: FrameStream slots (frames in flight)")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import FrameStream, inference
