@@ -120,7 +120,9 @@ class FrameStream:
         fs = FrameStream(net, (Hs, Ws), new_size=(240, 320))
         for pts, feat, out in fs.map(frames): ...          # or fs.submit(frame) ... fs.result()
 
-    ``out`` holds the slot's static device tensors: valid until ``slots`` further frames have been submitted.
+    ``out`` holds the slot's static device tensors: valid until ``slots`` further frames have been submitted (in ``map``:
+    until the next iteration).  Work enqueued on the caller's current stream before that submit still sees them intact:
+    ``submit`` orders the slot's replay behind the caller's stream.
     """
 
     def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=7):
@@ -236,6 +238,11 @@ class FrameStream:
                 self.dev_in[s].copy_(self.pin_in[s], non_blocking=True)
                 self.ev_up[s].record(self.copy_stream)
         cs = self.compute_streams[s]
+        # The replay overwrites this slot's static outputs.  Whatever the caller has enqueued on ITS stream to read the
+        # tensors of the frame that last used the slot (a clone, a matcher) must run first: order the slot's stream
+        # behind the caller's.  (Without it the reuse raced with such reads — seen once in four runs of the test suite
+        # with seven slots in flight.)
+        cs.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(cs):
             if not self.zero_copy:
                 cs.wait_event(self.ev_up[s])
