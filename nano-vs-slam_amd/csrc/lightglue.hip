@@ -1,10 +1,14 @@
 // LightGlue matcher kernels (reference: lightglue/lightglue.py; inference path, flash = False, no early stopping /
 // point pruning).  Descriptor width D <= 64 (configs S / A: 32, F: 64), 4 heads, <= 1024 keypoints per image: the
-// whole matcher is ~2 GFLOP per image pair and launch/latency bound, so the token-wise layers are plain fp32 FMAs (the
-// attention products use the fp32-grade split-fp16 MFMA kernel of attention.hip) and the kernels are row-wise: both images' tokens live in ONE row-major buffer [B*M rows of image 0 | B*N rows of image 1] so that every
-// per-token layer (Linear, rotary, LayerNorm, GELU, residual) is a single launch over all tokens of the batch.
+// whole matcher is ~2 GFLOP per image pair and launch/latency bound (23 launches of 5-34 us per forward).  The kernels
+// are row-wise: both images' tokens live in ONE row-major buffer [B*M rows of image 0 | B*N rows of image 1] so that
+// every per-token layer (Linear, rotary, LayerNorm, GELU, residual) is a single launch over all tokens of the batch.
+// D = 32: the token-wise products run on the matrix cores in split-fp16 (fp32-grade, as the attention products of
+// attention.hip); D = 64 and the input projection: plain fp32 FMAs.
 //
 //  lg_posenc_kernel     normalize_keypoints (:137-149) + LearnableFourierPositionalEncoding (:168-173)
+//  lg_tail_mfma_kernel  D = 32: out_proj / to_out + ffn + residual + the NEXT projection (cross to_qk | to_v, next Wqkv with
+//                       rotary, final_proj) of a transformer block in one launch (:247-261, :303-327)
 //  lg_linear_kernel     Y = X W^T + b with fused epilogues: rotary on the q|k columns (:158-159, :253-257),
 //                       LayerNorm + GELU (ffn.1, ffn.2), residual add (x + ffn(...), :261)
 //  (attention)          attention.hip: softmax(q k^T / sqrt(d)) v, streaming, split-fp16 matrix cores (:208-224, :312-321)
@@ -12,7 +16,6 @@
 //  lg_finalize_kernel   sigmoid_log_double_softmax (:363-376) + per-tile row / column max, argmax (filter_matches :403-404)
 //  lg_filter_kernel     mutual check, threshold, match scores (:405-416)
 #include <cstdlib>
-#include <type_traits>
 #include "kp2d_kernels.h"
 #include "device_guard.h"
 
