@@ -302,6 +302,22 @@ def test_select_and_gather_equals_the_two_calls():
         assert torch.equal(fi, idx) and torch.equal(fv, val) and torch.equal(fc, cnt)
         assert torch.equal(fp, pts) and torch.equal(fd, dsel)
         assert fp.shape == (3, min(k, n), 2) and fd.shape == (3, min(k, n), cd)
+    # many frames, dense selection: the gather that stages whole channel planes in LDS (post.hip gather_lds_kernel),
+    # against plain indexing
+    for B, (hc, wc), cd, k, thr in [(40, (8, 12), 32, 60, 0.3), (32, (30, 40), 64, 1000, 0.7), (36, (60, 80), 32, 1024, -np.inf)]:
+        n = hc * wc
+        s = rng.random((B, 1, hc, wc)).astype(np.float32)
+        s[1] = 0.0
+        coord = rng.random((B, 2, hc, wc)).astype(np.float32) * 300
+        desc = rng.standard_normal((B, cd, hc, wc)).astype(np.float32)
+        idx, val, cnt, pts, dsel = select_and_gather(*(torch.from_numpy(v).to(DEV) for v in (s, coord, desc)), k, thr)
+        idx, cnt, pts, dsel = idx.cpu().numpy(), cnt.cpu().numpy(), pts.cpu().numpy(), dsel.cpu().numpy()
+        for b in range(B):
+            m = int(cnt[b])
+            sel = idx[b, :m]
+            assert np.array_equal(dsel[b, :m], desc[b].reshape(cd, n)[:, sel].T)
+            assert np.array_equal(pts[b, :m], coord[b].reshape(2, n)[:, sel].T)
+            assert not dsel[b, m:].any() and not pts[b, m:].any() and np.all(idx[b, m:] == -1)
 
 
 def test_post_processing_accepts_any_forward_dict():
