@@ -448,10 +448,12 @@ constexpr int LG_TP = 68;      // pitch (floats) of the LDS tile that global row
 
 // thread (ty = tid/16, tx = tid%16) owns rows i0 + 4 ty + r, columns j0 + 4 tx + c of the tile
 __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
-  __shared__ __attribute__((aligned(16))) float at[64 * 64], bt[64 * 64];   // [k][row]
-  __shared__ float tile[64 * LG_TP];
+  extern __shared__ __attribute__((aligned(16))) float lg_sm[];             // at[D][64] | bt[D][64] | tile[64][LG_TP]
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, D = a.D, M = a.M, N = a.N;
+  float* const at = lg_sm;                   // [k][row]
+  float* const bt = at + 64 * D;
+  float* const tile = bt + 64 * D;
   const float* f0 = a.fz + (size_t)b * M * a.fs;
   const float* f1 = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs;
   // (a run-time-bounded loop with the loads inside is not unrolled: its round trips to L2 ran one after the other,
@@ -761,9 +763,10 @@ __global__ __launch_bounds__(256) void lg_filter_kernel(const LgAssignArgs a) {
 }
 
 int launch_lg_assign(const LgAssignArgs& a, hipStream_t s) {
-  if (a.D < 1 || a.D > 64 || a.M < 1 || a.N < 1) return -1803;
+  if (a.D < 8 || a.D > 64 || (a.D & 3) || a.M < 1 || a.N < 1) return -1803;
   const dim3 tiles((a.N + 63) / 64, (a.M + 63) / 64, a.B);
-  hipLaunchKernelGGL(lg_sim_kernel, tiles, dim3(256), 0, s, a);
+  // (D >= 8: the cross-wave scratch of the column sums reuses the first 512 floats of at)
+  hipLaunchKernelGGL(lg_sim_kernel, tiles, dim3(256), (size_t)(2 * 64 * a.D + 64 * LG_TP) * sizeof(float), s, a);
   hipLaunchKernelGGL(lg_finalize_kernel, tiles, dim3(256), 0, s, a);
   hipLaunchKernelGGL(lg_filter_kernel, dim3((a.M + a.N + 255) / 256, a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
