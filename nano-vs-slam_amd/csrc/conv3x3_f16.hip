@@ -29,6 +29,7 @@
 #include "conv_common.h"
 #include "device_guard.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace kp2d {
 
@@ -339,6 +340,218 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 #undef EPI_TH
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-chunk layers (conv1b: 16 -> 32 channels at full resolution, max-pooled output): warp-specialised and persistent.
+// With one chunk a workgroup of the kernel above is load -> commit -> multiply -> store with nothing of its own to overlap,
+// and the layer ran at (memory time + matrix time): 0.171 ms for 0.086 + 0.090.  (A persistent loop in which every wave
+// does both jobs lost, r3_ab_persistent.txt: the compiler merges a wave's waits over the loop's predecessors and the first
+// loads of a tile wait for the previous tile's stores.)  Here the jobs belong to DIFFERENT waves, each with its own
+// counters: waves 8-11 only stage (global -> registers -> split -> LDS image of tile i + 1, the loads of tile i + 2 already
+// in flight), waves 0-7 only multiply tile i out of the other image and store its pooled result; one barrier per tile; the
+// nine weight slots stay in LDS for the whole launch.  One 768-thread workgroup per CU walks tiles g, g + G, ...
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WS_TH = 16, WS_TW = 32, WS_PITCH = 36, WS_ROWS = WS_TH + 2, WS_COLS = WS_TW + 2;
+constexpr int WS_LO = WS_ROWS * WS_PITCH * F_PXB;      // byte offset of an image's lo plane (20,736)
+constexpr int WS_IMG = 2 * WS_LO;                      // one input image (41,472 B)
+constexpr int WS_N = 32, WS_WL = 9 * WS_N * 32;        // channels; byte offset of the wl plane behind the wh plane
+constexpr int WS_W = 2 * WS_IMG;                       // weight planes behind the two images
+constexpr int WS_LDS = WS_W + 2 * WS_WL;               // 101,376 B
+constexpr int WS_G = WS_ROWS * WS_COLS * 4;            // 16-byte granules of a halo tile (2448)
+constexpr int WS_IT = (WS_G + 255) / 256;              // per staging thread (10)
+}  // namespace
+
+__global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const sm = reinterpret_cast<char*>(smem);
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave8 < 8;                   // waves 0-7 multiply (two per SIMD), waves 8-11 stage
+  const int H = a.H, W = a.W, per_frame = a.tiles_x * a.tiles_y;
+  constexpr int OOB = 0x7ffffff0;
+
+  // weights: the chunk's [slot][n][16 hi | 16 lo] rows -> [wh plane | wl plane] (as the kernel above), once
+  for (int gi = tid; gi < 9 * WS_N * 4; gi += 768)
+    *reinterpret_cast<float4*>(sm + WS_W + (gi >> 2) * 32 + (gi & 1) * 16 + ((gi >> 1) & 1) * WS_WL) =
+        reinterpret_cast<const float4*>(a.w)[gi];
+
+  // ---- producer state: granule gi = ptid + 256 it of a halo tile = (halo pixel gi / 4, channels 4 (gi % 4) ..) ----
+  const int ptid = tid - 512;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in0.p + a.in0.o), 0, (int)(((long)a.B * a.in0.bs - a.in0.o) * 4), 0x00020000);
+  const int ps = (int)a.in0.ps * 4;                   // pixel stride, bytes
+  // TWO register sets: a CU has one workgroup, so the bytes it keeps in flight are what its staging waves hold — with one
+  // set (41 KB per CU) the layer could not pass ~2.8 TB/s whatever else overlapped
+  float4 rin[2][WS_IT];
+  auto request = [&](int t, auto set_c) {             // issue the loads of tile t (past the last tile: zeros, same count)
+    constexpr int RS = decltype(set_c)::value;
+    const bool live = t < ntiles;
+    const int b = t / per_frame, r = t - b * per_frame;
+    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    const int y0 = ty * WS_TH - 1, x0 = tx * WS_TW - 1;
+    const int fb = b * (int)a.in0.bs * 4;
+#pragma unroll
+    for (int it = 0; it < WS_IT; ++it) {
+      const int gi = ptid + 256 * it, hp = gi >> 2;
+      const int py = hp / WS_COLS, px = hp - py * WS_COLS;
+      const int gy = y0 + py, gx = x0 + px;
+      const bool ok = live && gi < WS_G && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int off = ok ? fb + (gy * W + gx) * ps + (gi & 3) * 16 : OOB;
+      rin[RS][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+  };
+  auto commit = [&](int buf, auto set_c) {            // registers -> split -> image buf
+    constexpr int RS = decltype(set_c)::value;
+#pragma unroll
+    for (int it = 0; it < WS_IT; ++it) {
+      const int gi = ptid + 256 * it, hp = gi >> 2;
+      if (gi >= WS_G) continue;
+      const int py = hp / WS_COLS, px = hp - py * WS_COLS;
+      const int lb = buf * WS_IMG + (py * WS_PITCH + px) * F_PXB + (gi & 3) * 8;
+      const float4 v = rin[RS][it];
+      f16x2 h0, h1, l0, l1;
+      split2(v.x, v.y, h0, l0);
+      split2(v.z, v.w, h1, l1);
+      *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<f16x4*>(sm + WS_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+  };
+
+  // ---- consumer state: wave (w, ph) owns tile rows 4 w .. 4 w + 3 x columns 16 ph .. + 15 = four M-tiles (2 x 8 pixels),
+  //      two N-tiles (one lone multiplying wave per SIMD cannot hide its own LDS latency: 0.191 ms against 0.178 for the
+  //      kernel above; two per SIMD as there) ----
+  constexpr int MT = 4, NN = 2, CB = 2;
+  const int lg = lane >> 4, lp = lane & 15;
+  const int wr = wave8 & 3, ph = (wave8 >> 2) & 1;
+  const int a0 = ((wr * 4 + ((lp >> 1) & 1)) * WS_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * F_PXB + 16 * (lg & 1);
+  const int a_dx = a0 + (lg >> 1) * F_PXB;
+  const int a_dy = a0 + (lg >> 1) * WS_PITCH * F_PXB;
+  const int a_s = a0 + (lg >> 1) * WS_LO;
+  const int b_s = WS_W + lp * 32 + 16 * (lg & 1);
+  const int b_p = b_s + (lg >> 1) * WS_N * 32;
+  auto tap_off = [](int t) constexpr { return ((t / 3) * WS_PITCH + (t % 3)) * F_PXB; };
+  const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
+  const int Hp = H >> 1, Wp = W >> 1;
+  float sc[NN], sh[NN];
+#pragma unroll
+  for (int n = 0; n < NN; ++n) { sc[n] = a.scale[n * 16 + lp]; sh[n] = a.shift[n * 16 + lp]; }
+
+  auto multiply = [&](int t, int buf) {
+    const int b = t / per_frame, r = t - b * per_frame;
+    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    const int y0 = ty * WS_TH, x0 = tx * WS_TW;
+    if (y0 + 4 * wr >= H || x0 + 16 * ph >= W) return;      // rows / columns wholly outside the map (ragged tiles)
+    f32x4 acc[MT][NN];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ib = buf * WS_IMG;
+#pragma unroll
+    for (int slot = 0; slot < 9; slot += 2) {
+      const int tp = slot_tap(slot);
+      const bool single = slot == 8;
+      const bool dy = slot == 4;
+      const int ab = ib + (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(tp);
+      const int bb = (single ? b_s : b_p) + slot * WS_N * 32;
+      f16x8 bh[NN], bl[NN];
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        bh[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512);
+        bl[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512 + WS_WL);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mo = (2 * (m / CB) * WS_PITCH + 8 * (m % CB)) * F_PXB;
+        if (single) {
+          const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
+          }
+        } else {
+          const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+          const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + WS_LO);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // pooled epilogue (conv_epilogue.inc, ST_NHWC_POOL): the four registers of a lane are one 2 x 2 pixel block
+    unsigned* o1 = reinterpret_cast<unsigned*>(a.out1) + (size_t)b * Hp * Wp * a.os1;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      const int co = n * 16 + lp;
+      const bool cok = co < a.cout;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float tt = fmaf(acc[m][n][r], sc[n], sh[n]);
+          v[r] = fmaxf(tt, tt * slope);
+        }
+        const int yp = (y0 + wr * 4 + 2 * (m / CB)) >> 1, xp = (x0 + 16 * ph + 8 * (m % CB) + 2 * lg) >> 1;
+        const float vmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (cok && yp < Hp && xp < Wp) o1[(yp * Wp + xp) * a.os1 + a.oo1 + co] = __float_as_uint(vmax);
+      }
+    }
+  };
+
+  // Tile i of this workgroup is t0 + i G.  Staging waves: set 0 carries the odd tiles (and tile 0), set 1 the even ones;
+  // in iteration i they commit tile i + 1 into image (i + 1) & 1 and request tile i + 3 into the set just freed.  Every
+  // request / commit runs unconditionally (tiles past the end load and commit zeros nobody reads), so that each path has
+  // the same number of loads in flight and the waits in front of a commit stay partial.
+  // The two jobs are two separate loops with the same barrier count (one before, two per trip): in a shared loop the
+  // staging registers would be live through the multiply code as far as the compiler can tell (57 spilled registers).
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int G = gridDim.x, t0 = blockIdx.x;
+  if (consumer) {
+    __syncthreads();
+    for (int t = t0; t < ntiles; t += 2 * G) {
+      multiply(t, 0);
+      __syncthreads();
+      if (t + G < ntiles) multiply(t + G, 1);
+      __syncthreads();
+    }
+  } else {
+    request(t0, S0{});
+    commit(0, S0{});
+    request(t0 + G, S0{});
+    request(t0 + 2 * G, S1{});
+    __syncthreads();
+    for (int t = t0; t < ntiles; t += 2 * G) {
+      commit(1, S0{});
+      request(t + 3 * G, S0{});
+      __syncthreads();
+      commit(0, S1{});
+      request(t + 4 * G, S1{});
+      __syncthreads();
+    }
+  }
+}
+
+static int launch_ws(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  a.tiles_x = (a.W + WS_TW - 1) / WS_TW;
+  a.tiles_y = (a.H + WS_TH - 1) / WS_TH;
+  const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
+  static PerDeviceOnce lds_once;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel))) return e;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = (int)(ntiles < cus ? ntiles : cus);
+  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel, dim3(grid), dim3(768), WS_LDS, s, a, (int)ntiles);
+  return (int)hipGetLastError();
+}
+
 template <int NH, int NP, int TH = TILE>
 static int launch_f(const ConvArgs& a0, hipStream_t s) {
   constexpr int N = NH * 32, TW = tile_w(NH, NP, TH);
@@ -379,6 +592,12 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   }
   // 32-channel layers on grids that fill the chip anyway: 16 x 32 pixel tiles (one weight slab per 512 pixels, 16 waves
   // per CU).  Small grids keep the 16 x 16 tiles (twice the workgroups, half as long: single frames).  KP2D_WIDE=0: never.
+  // single-chunk, max-pooled, 32 channels (conv1b) on grids that fill the chip several times: warp-specialised persistent form
+  static const bool ws_on = !(getenv("KP2D_WS") && getenv("KP2D_WS")[0] == '0');
+  if (ws_on && a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.store == ST_NHWC_POOL && a.act <= ACT_RELU &&
+      !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= 1024 &&
+      (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
+    return launch_ws(a, s);
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
   // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)
