@@ -59,11 +59,15 @@ __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ?
 //     NH = NP = 1, TH = 8 is the single-frame form: a wave owns two pixel rows (two M-tiles,
 //     16 accumulators), so a layer of a 60 x 80 map is 80 workgroups of half the length instead of 40 — a frame's ~25
 //     dependent launches are each as long as ONE workgroup's serial chain.
-template <int NH, int NP, int TH>
+// FLAT32: the 256-thread form on 8 x 32 pixel tiles (a wave owns two rows x 32 columns = four M-tiles, as on 16 x 16) for
+//     the planar-output 32-channel layers on maps with a half-empty last 16-row tile row: no ragged row, and every row
+//     of a channel plane a workgroup writes is a whole 128-byte line.
+template <int NH, int NP, int TH, bool FLAT32 = false>
 __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
   static_assert(NH * NP <= 2, "one workgroup is 256 or 512 threads");
   static_assert(TH == 16 || (TH == 8 && NP == 1), "8-row tiles: the 256-thread form (16 wide) and the 64-channel form (32 wide)");
-  constexpr int TW = tile_w(NH, NP, TH);            // tile width in pixels
+  static_assert(!FLAT32 || (NH == 1 && NP == 1 && TH == 8), "the flat 32-wide form is a 256-thread form");
+  constexpr int TW = FLAT32 ? 32 : tile_w(NH, NP, TH);      // tile width in pixels
   constexpr int RW = TH / 4;                        // pixel rows per wave
   constexpr int CB = TW / (8 * NP);                 // 8-pixel column blocks per wave
   constexpr int F_ROWS = TH + 2, MT = (RW / 2) * CB;      // halo rows; M-tiles (2 x 8 pixels) per wave
@@ -552,9 +556,9 @@ static int launch_ws(const ConvArgs& a0, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-template <int NH, int NP, int TH = TILE>
+template <int NH, int NP, int TH = TILE, bool FLAT32 = false>
 static int launch_f(const ConvArgs& a0, hipStream_t s) {
-  constexpr int N = NH * 32, TW = tile_w(NH, NP, TH);
+  constexpr int N = NH * 32, TW = FLAT32 ? 32 : tile_w(NH, NP, TH);
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
   a.tiles_y = (a.H + TH - 1) / TH;
@@ -568,11 +572,11 @@ static int launch_f(const ConvArgs& a0, hipStream_t s) {
   if ((a.dbg & 128) && NH == 2) lds += 35 * 1024;
 #endif
   static PerDeviceOnce lds_once;      // per device: a handle may live on any visible device
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP, TH>))) return e;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_kernel<NH, NP, TH, FLAT32>))) return e;
   const int grid = a.tiles_x * a.tiles_y * a.B;
   const int groups = a.npad / N;
   if (a.store == ST_NCHW && groups != 1 && a.act == ACT_SOFTMAX_C) return -1002;  // class softmax needs one group
-  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH, NP, TH>), dim3(grid, groups), dim3(256 * NH * NP), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_f16x3_kernel<NH, NP, TH, FLAT32>), dim3(grid, groups), dim3(256 * NH * NP), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -602,6 +606,14 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
   // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)
   if (wide_on && a.store != ST_NCHW && a.W >= 32 && wide_tiles >= 1024 && (long)a.H * a.W < (1L << 20)) return launch_f<1, 2>(a, s);
+  // planar outputs on maps with a half-empty last 16-row tile row (confBb / the class map at 120 rows): 8 x 32 tiles
+  {
+    static const bool flat_on = !(getenv("KP2D_FLAT") && getenv("KP2D_FLAT")[0] == '0');
+    const int rag = a.H & 15;
+    if (flat_on && a.store == ST_NCHW && rag >= 1 && rag <= 8 && a.W >= 32 && !(a.W & 3) && (long)a.H * a.W < (1L << 20) &&
+        (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * (a.npad / 32) >= 512)
+      return launch_f<1, 1, 8, true>(a, s);
+  }
   // single frames (the grid of 16 x 16 tiles would leave most CUs idle): 8-row tiles, twice the workgroups, half as long
   static const bool short_on = !(getenv("KP2D_SHORT") && getenv("KP2D_SHORT")[0] == '0');
   if (short_on && (long)a.tiles_x * a.tiles_y * a.B * (a.npad / 32) < 256) return launch_f<1, 1, 8>(a, s);
