@@ -199,6 +199,28 @@ def test_full_size_properties():
         assert (val[b, 1:n] <= val[b, : n - 1]).all()
 
 
+def test_warp_specialised_conv1b_equals_the_general_kernel_on_ragged_tiles():
+    """backbone.conv1b runs as the warp-specialised persistent kernel once a launch has >= 1024 tiles (conv3x3_f16.hip);
+    sub-batches of one frame take the general kernel.  272 columns = 8.5 tiles of 32: the last tile column is ragged."""
+    model, _ = product_model("S", False, 28)
+    B, H, W = 20, 208, 272      # two stream lanes of 10 frames = 1170 tiles each
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=5)).to(DEV)
+    eng_ready = model(x[:1])          # creates the engine
+    del eng_ready
+    eng = model._engine
+    with torch.no_grad():
+        eng.lib.kp2d_set_chunk_frames(eng.handle, 0)
+        eng._ws = None
+        a = {k: v.clone() for k, v in model(x).items()}
+        eng.lib.kp2d_set_chunk_frames(eng.handle, 1)
+        eng._ws = None
+        c = model(x)
+        eng.lib.kp2d_set_chunk_frames(eng.handle, 0)
+        eng._ws = None
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
+
+
 def test_cfg4_full_size_properties():
     """BASELINE configs[3] per-GPU share: V3 S_A (efficient self-attention on) at 480x640 x 32 frames, 19 classes.
     This size runs in sub-batches under the 4 GiB workspace cap; results must not depend on that: batch permutation
