@@ -2,7 +2,13 @@
 """Headline benchmark: frames/sec of the KP2DTiny-S 240x320 multi-task inference path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one rank per GPU either way it is started:
+  * under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...): the
+    process IS a rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; WORLD_SIZE != --gpus is refused);
+  * started plainly (no WORLD_SIZE in the environment): this process only launches — before anything touches the GPU it
+    starts N fresh child processes of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set, relays rank 0's JSON line and exits with the worst child code (self_launch()).
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
 ``model(x)`` (backbone + score/loc/descriptor/segmentation/NetVLAD heads) + ``post_processing`` +
@@ -61,6 +67,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("KP2D_PRECISION", "f16x3"), choices=["f16x3", "fp32"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only: every rank joins the process group, one all_gather, rank 0 prints a line marked "
+                         "dry_run with no throughput in it (checks the launch path on a box without a GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                                                       "rehearsing the multi-rank path on a single-GPU box)")
     return ap.parse_args()
@@ -175,8 +184,86 @@ def file_commit(rel):
         return "unknown"
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves.
+
+    The parent never initialises the GPU (it only parses arguments and waits), the children are fresh interpreters
+    (subprocess, no fork of a HIP context, no exec from a process that has touched the device).  Rank 0's stdout is
+    relayed line by line to stdout, the other ranks' stdout goes to stderr; stderr passes through.  Exit
+    code = the worst child code; a rank that dies takes the others down after a grace period instead of leaving
+    them waiting in a collective."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+                LOCAL_WORLD_SIZE=str(args.gpus), KP2D_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def relay(p, r):
+        for ln in p.stdout:
+            if r == 0:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            elif not ln.startswith("{"):
+                sys.stderr.write(f"[rank {r}] {ln}")
+
+    threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    worst, deadline = 0, None
+    alive = set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is not None:
+                alive.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    if deadline is None:
+                        deadline = time.monotonic() + 30.0      # the others are probably stuck in a collective
+        if deadline is not None and time.monotonic() > deadline:
+            for r in alive:
+                procs[r].kill()                                  # exact PIDs we started, nothing else
+            deadline = None
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    return worst
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the launch + rendezvous path only (no device, no kernels, no throughput)."""
+    import torch.distributed as dist
+    seen = [rank]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mine = torch.tensor([rank], dtype=torch.int64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        seen = sorted(int(v.item()) for v in every)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (rendezvous only, nothing measured)", "dry_run": True, "value": None,
+                          "n_gpus": world, "collective": {"backend": "gloo", "ranks_seen": len(seen), "ranks": seen},
+                          "launcher": "self (bench.py started its own ranks)" if os.environ.get("KP2D_BENCH_SELF_LAUNCHED")
+                          else "external (torchrun or equivalent)"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +271,8 @@ def main():
         # the line's n_gpus must be what was asked for AND what ran: refuse anything else
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with python -m torch.distributed.run "
                          f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
     dev_index = local_rank % torch.cuda.device_count()     # one rank per GPU; wraps only in single-GPU rehearsals
@@ -343,6 +432,7 @@ def main():
         }
         if collective is not None:
             line["collective"] = collective
+            line["launcher"] = "self (bench.py started its own ranks)" if os.environ.get("KP2D_BENCH_SELF_LAUNCHED") else "external (torchrun or equivalent)"
             fr = rank_fps.get(args.precision, [])
             if fr:
                 line["per_rank_frames_per_s"] = {"min": round(min(fr), 1), "max": round(max(fr), 1)}

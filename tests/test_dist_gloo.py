@@ -1,12 +1,15 @@
 """Multi-process path of sharding.py on CPU: world_size 2, gloo backend, 127.0.0.1 rendezvous."""
 import os
 import socket
+import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from conftest import ROOT
 from nano_vs_slam_amd.sharding import broadcast_blob, gather_vlad, shard_range
 
 
@@ -113,3 +116,34 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 8" in (r.stderr + r.stdout)
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the way the driver runs --gpus 1) must start N
+    ranks by itself: the parent spawns fresh children before anything touches a device, relays rank 0's one JSON line
+    and the worst child code.  --dry-run = rendezvous only (this box has no GPU); the measured twin of this test is
+    tests/test_multi_rank_gpu.py::test_bench_self_launch_two_ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["collective"]["ranks_seen"] == 2
+    assert j["collective"]["ranks"] == [0, 1] and j["launcher"].startswith("self")
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """No device here: the real (non-dry) run must fail in every child and the parent must return non-zero, not hang."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "needs a HIP device" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

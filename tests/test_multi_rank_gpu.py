@@ -127,3 +127,19 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE: bench.py starts its two ranks itself (both on
+    this box's one GPU, gloo control plane), one JSON line, ranks_seen == 2 — the command shape the driver uses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--global-batch", "12", "--steps", "3", "--warmup", "1",
+                        "--height", "64", "--width", "96", "--backend", "gloo", "--profile-steps", "1", "--no-precision-modes"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["collective"]["ranks_seen"] == 2 and j["launcher"].startswith("self")
+    assert j["config"]["global_batch"] == 12 and j["value"] > 0
