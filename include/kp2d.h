@@ -189,6 +189,14 @@ int kp2d_get_precision(const kp2d_model* m);
 int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_floats);
 /* frames per internal sub-batch (0 = automatic).  Intermediates of one sub-batch stay in the 256 MB Infinity Cache. */
 int kp2d_set_chunk_frames(kp2d_model* m, int frames);
+/* Tuning knobs of the engine (never needed for correct results; used by the A/B scripts and the parity tests to force a
+ * kernel form).  Keys:
+ *   "wsm_min_items"  least number of (16 x 32 pixel tile, 64-channel group) work items of a launch for the
+ *                    warp-specialised persistent form of the multi-chunk 3x3 layers (conv3x3_wsm.hip);
+ *                    0 = default (KP2D_WSM or 256 = one item per CU), -1 = never.
+ * Unknown keys return KP2D_ERR_ARG.  kp2d_profile_get reports the tile form each conv launch took behind its kernel
+ * family ("conv3x3_f16x3<wsm>", "conv3x3_f16x3<2,1,16>", ...). */
+int kp2d_set_option(kp2d_model* m, const char* key, long value);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "kp2d_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _F,
                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kp2d_set_chunk_frames": (C.c_int, [_P, C.c_int]),
+    "kp2d_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "kp2d_set_precision": (C.c_int, [_P, C.c_int]),
     "kp2d_get_precision": (C.c_int, [_P]),
     "kp2d_set_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),

@@ -13,7 +13,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv3x3.hip", "conv3x3_f16.hip", "head3x3.hip", "netvlad.hip", "post.hip", "attention.hip", "match.hip", "lightglue.hip", "kp2d_api.cpp",
+SOURCES = ["conv3x3.hip", "conv3x3_f16.hip", "conv3x3_wsm.hip", "head3x3.hip", "netvlad.hip", "post.hip", "attention.hip", "match.hip", "lightglue.hip", "kp2d_api.cpp",
            "lightglue_api.cpp"]
 HEADERS = ["kp2d_kernels.h", "device_guard.h", "device_logic.h", "conv_common.h", "conv_epilogue.inc", os.path.join("..", "..", "include", "kp2d.h"),
            os.path.join("..", "..", "include", "kp2d_lightglue.h")]
@@ -29,17 +29,21 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
+    """ablate=True: the timing-ablation build (-DKP2D_ABLATE: KP2D_DBG bits switch phases of the conv kernels off,
+    results are then wrong by design) into build_exp/libkp2d_ablate.so — selected with KP2D_LIB, never the product."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_exp", "obj_ablate") if ablate else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(HERE, "build_exp", "libkp2d_ablate.so") if ablate else LIB
+    flags = FLAGS + (["-DKP2D_ABLATE"] if ablate else [])
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src + ".o")
         path = os.path.join(HERE, src)
         if force or _stale(obj, [path] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [HIPCC] + flags + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=HERE)
@@ -47,13 +51,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=HERE)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

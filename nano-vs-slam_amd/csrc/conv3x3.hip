@@ -343,6 +343,7 @@ int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s) {
   // npad is 32, or a multiple of 64 handled as npad/64 channel groups (blockIdx.y)
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32 || a.ng32;
+  conv3x3_note_variant("");
   if (a.prec == 1) {
     if (kc != 16) return -1003;
     if (a.taps == 9) return launch_conv3x3_f16x3(a, s);      // conv3x3_f16.hip

@@ -580,6 +580,10 @@ static int launch_f(const ConvArgs& a0, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+namespace { thread_local const char* g_variant = ""; }
+const char* conv3x3_last_variant() { return g_variant; }
+void conv3x3_note_variant(const char* v) { g_variant = v; }
+
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.taps != 9 || a.prec != 1) return -1000;
   // the staging addresses a source pixel as (y * W + x) * pixel stride
@@ -588,10 +592,20 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.npad != 32 && a.npad % 64 != 0) return -1000;
   const bool one = a.npad == 32 || a.ng32;
   if (!one) {
+    // multi-chunk layers with 64-channel groups on grids that fill the chip: warp-specialised persistent form
+    // (conv3x3_wsm.hip).  KP2D_WSM = least number of (tile, group) work items (256 = one per CU), 0 = never (the default
+    // until the form wins end to end: DESIGN.md section 5, round 4).
+    static const long wsm_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : 0;
+    const long wsm_min = a.wsm_min ? a.wsm_min : wsm_env;
+    if (wsm_min > 0) {
+      const int e = launch_conv3x3_f16x3_wsm(a, s, wsm_min);
+      if (e != -1000) { g_variant = "<wsm>"; return e; }
+    }
     // map heights that leave the last 16-row tile row at most half full (120 = 7.5 x 16): 8 x 32 tiles, no ragged row
     static const bool flat_on = !(getenv("KP2D_FLAT") && getenv("KP2D_FLAT")[0] == '0');
     const int rag = a.H & 15;
-    if (flat_on && rag >= 1 && rag <= 8 && a.W >= 32 && (long)a.H * a.W < (1L << 20)) return launch_f<2, 1, 8>(a, s);
+    if (flat_on && rag >= 1 && rag <= 8 && a.W >= 32 && (long)a.H * a.W < (1L << 20)) { g_variant = "<2,1,8>"; return launch_f<2, 1, 8>(a, s); }
+    g_variant = "<2,1,16>";
     return launch_f<2, 1>(a, s);
   }
   // 32-channel layers on grids that fill the chip anyway: 16 x 32 pixel tiles (one weight slab per 512 pixels, 16 waves
@@ -601,22 +615,23 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (ws_on && a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.store == ST_NHWC_POOL && a.act <= ACT_RELU &&
       !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= 1024 &&
       (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
-    return launch_ws(a, s);
+  { g_variant = "<ws>"; return launch_ws(a, s); }
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
   // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)
-  if (wide_on && a.store != ST_NCHW && a.W >= 32 && wide_tiles >= 1024 && (long)a.H * a.W < (1L << 20)) return launch_f<1, 2>(a, s);
+  if (wide_on && a.store != ST_NCHW && a.W >= 32 && wide_tiles >= 1024 && (long)a.H * a.W < (1L << 20)) { g_variant = "<1,2,16>"; return launch_f<1, 2>(a, s); }
   // planar outputs on maps with a half-empty last 16-row tile row (confBb / the class map at 120 rows): 8 x 32 tiles
   {
     static const bool flat_on = !(getenv("KP2D_FLAT") && getenv("KP2D_FLAT")[0] == '0');
     const int rag = a.H & 15;
     if (flat_on && a.store == ST_NCHW && rag >= 1 && rag <= 8 && a.W >= 32 && !(a.W & 3) && (long)a.H * a.W < (1L << 20) &&
         (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * (a.npad / 32) >= 512)
-      return launch_f<1, 1, 8, true>(a, s);
+    { g_variant = "<1,1,8,flat32>"; return launch_f<1, 1, 8, true>(a, s); }
   }
   // single frames (the grid of 16 x 16 tiles would leave most CUs idle): 8-row tiles, twice the workgroups, half as long
   static const bool short_on = !(getenv("KP2D_SHORT") && getenv("KP2D_SHORT")[0] == '0');
-  if (short_on && (long)a.tiles_x * a.tiles_y * a.B * (a.npad / 32) < 256) return launch_f<1, 1, 8>(a, s);
+  if (short_on && (long)a.tiles_x * a.tiles_y * a.B * (a.npad / 32) < 256) { g_variant = "<1,1,8>"; return launch_f<1, 1, 8>(a, s); }
+  g_variant = "<1,1,16>";
   return launch_f<1, 1>(a, s);
 }
 

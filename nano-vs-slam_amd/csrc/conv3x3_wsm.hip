@@ -1,0 +1,398 @@
+// Multi-chunk 3x3 convolution layers with 64-channel groups in split-fp16 arithmetic: warp-specialised, persistent.
+//
+// Same operator and arithmetic as conv3x3_f16x3_kernel<2, 1, *> (conv3x3_f16.hip: AnnotatedConvBnReLUModel,
+// modules/base.py:14-46, inside BackBone modules/encoders.py:105-129, the heads modules/decoders/heads.py:38-104 and
+// SegmentationHead modules/decoders/segmentation.py:126-157): x = xh + xl, w = wh + wl (fp16 halves), fourteen
+// v_mfma_f32_16x16x32_f16 per 16-channel chunk and accumulator tile, the same slot order, the same LDS image layout.
+// What differs is WHO does what, and when.  There a 512-thread workgroup is load -> split -> commit -> barrier ->
+// multiply -> barrier per chunk, then an epilogue through LDS, and the phases of one workgroup overlap only with those of
+// the ONE other workgroup its CU holds: measured (profiles/r3_ablation_conv.txt) matrix time and everything else add up.
+// Here one 768-thread workgroup per CU walks work items (tile, 64-channel group) j0, j0 + G, ... as ONE flat sequence of
+// steps (item, chunk), with two roles on different waves, each with its own vmcnt:
+//   * waves 8-11 STAGE: the 18 x 34 halo image of step s + 1 goes registers -> hi / lo fp16 planes -> LDS stage (s + 1) & 1
+//     while the loads of steps s + 2 and s + 3 are in flight in two register sets, and the step's 36 KB weight slab is
+//     copied global -> LDS by buffer_load ... lds (no registers); nothing here ever waits for a multiply;
+//   * waves 0-7 MULTIPLY step s out of stage s & 1 — a wave owns 4 rows x 16 columns x ALL 64 channels of a 16 x 32 pixel
+//     tile (64 accumulator registers: half the weight-operand reads per MFMA of the 32-channel waves, and one weight slab
+//     per 512 pixels instead of per 256) — and, after an item's last chunk, store it straight from the accumulators.
+//     The products are TRANSPOSED (weights are the A operand, pixels the B operand), so a lane's four accumulator
+//     registers are four consecutive channels of ONE pixel: a 16-byte NHWC store, no transposition through LDS and no
+//     barrier in the epilogue; the pooled output is a quad max over four lanes (DPP).
+// One barrier per step; the first loads of the next item are in flight two steps before its first multiply, so an item's
+// load latency and its epilogue hide behind the neighbouring items' matrix work.
+//
+// Barrier contract: BOTH role loops run exactly 1 + wsm_padded_steps(nsteps) barriers (one before step 0, one after
+// every step, steps padded to an even count); the role branch is wave-uniform (readfirstlane of the wave index), every wave of the
+// workgroup executes every barrier, and no barrier sits under a condition that differs between waves of a role.
+#include "conv_common.h"
+#include "device_guard.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace kp2d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int M_TH = 16, M_TW = 32, M_PITCH = 36, M_ROWS = M_TH + 2, M_COLS = M_TW + 2, M_PXB = 32;
+constexpr int M_LO = M_ROWS * M_PITCH * M_PXB;         // byte offset of an image's lo plane (20,736)
+constexpr int M_IMG = 2 * M_LO;                        // one input image: hi plane | lo plane (41,472 B)
+constexpr int M_N = 64;                                // channels per work item
+constexpr int M_WL = 9 * M_N * 32;                     // byte offset of the wl plane behind the wh plane (18,432)
+constexpr int M_WSLAB = 2 * M_WL;                      // a chunk's weight slab (36,864 B)
+constexpr int M_STAGE = M_IMG + M_WSLAB;               // one stage: image | weights (78,336 B)
+constexpr int M_SS = 2 * M_STAGE;                      // scale | shift vectors behind the two stages (156,672)
+constexpr int M_MAXN = 256;                            // channels of a layer (scale / shift in LDS)
+constexpr int M_LDS = M_SS + 2 * M_MAXN * 4;           // 158,720 B
+constexpr int M_G = M_ROWS * M_COLS * 4;               // 16-byte granules of a halo image (2448)
+constexpr int M_PT = 256;                              // staging threads
+constexpr int M_IT = (M_G + M_PT - 1) / M_PT;          // granules per staging thread (10)
+constexpr int M_PIECES = M_WSLAB / 1024;               // 1-KiB LDS-DMA pieces of a weight slab (36)
+constexpr int M_PW = M_PIECES / 4;                     // per staging wave (9)
+constexpr int M_THREADS = 768;
+static_assert(M_PIECES % 4 == 0, "weight slab pieces must divide over the four staging waves");
+static_assert(M_LDS <= 160 * 1024, "LDS budget");
+
+__host__ __device__ constexpr int m_slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
+// barriers each role executes for `nsteps` steps (the ONE definition both loops are written against)
+__host__ __device__ constexpr int wsm_padded_steps(int nsteps) { return (nsteps + 1) & ~1; }
+
+struct WsmItem { int b, y0, x0, g; };
+}  // namespace
+
+__global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const ConvArgs a, const int nitems, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const sm = reinterpret_cast<char*>(smem);
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < 8;                    // wave-uniform by construction (see the barrier contract above)
+  const int H = a.H, W = a.W;
+  const int groups = a.npad / M_N;
+  const int nchunk = a.cin >> 4;
+  const int c0 = a.in0.c;
+  constexpr int OOB = 0x7ffffff0;
+
+  // ---- this workgroup's items: j = i G + off; every XCD (workgroups t0 = x mod 8) owns a contiguous run per round ----
+  const int G = gridDim.x, t0 = blockIdx.x;
+  const int off = (t0 & 7) * (G >> 3) + (t0 >> 3);
+  const int n_my = (nitems - off + G - 1) / G;      // >= 1: the launcher keeps G <= nitems
+  const int nsteps = n_my * nchunk;
+  const int nsteps_p = wsm_padded_steps(nsteps);
+  // item j -> (tile u = j / groups, group j % groups); tiles of the LAST tile row come last (they are the cheap ones on
+  // maps with a ragged last row, so that the static schedule ends on them everywhere)
+  const int tx_n = a.tiles_x, ty_n = a.tiles_y;
+  const int per_full = tx_n * (ty_n - 1), nfull = per_full * a.B;
+  auto decode = [&](int i) -> WsmItem {
+    const int j = i * G + off;
+    const int u = j / groups;
+    WsmItem r;
+    r.g = j - u * groups;
+    if (u < nfull) {
+      r.b = u / per_full;
+      const int q = u - r.b * per_full, ty = q / tx_n;
+      r.y0 = ty * M_TH; r.x0 = (q - ty * tx_n) * M_TW;
+    } else {
+      const int v = u - nfull;
+      r.b = v / tx_n;
+      r.y0 = (ty_n - 1) * M_TH; r.x0 = (v - r.b * tx_n) * M_TW;
+    }
+    return r;
+  };
+
+  // per-channel scale | shift of the whole layer -> LDS (the multiplying waves read 4 channels per ds_read_b128)
+  for (int c = tid; c < a.npad; c += M_THREADS) {
+    smem[M_SS / 4 + c] = a.scale[c];
+    smem[M_SS / 4 + M_MAXN + c] = a.shift[c];
+  }
+
+  if (!consumer) {
+    // =================================== staging waves ===================================
+    __builtin_amdgcn_s_setprio(1);                   // their short bursts go ahead of the multiplying waves' issue
+    const int ptid = tid - 512, pw = wave - 8;
+    // granule gi = ptid + 256 it of a halo image = (halo pixel hp = gi / 4 = (py, px), channels 4 (gi % 4) ...)
+    int g_pix[M_IT], g_yx[M_IT];
+#pragma unroll
+    for (int it = 0; it < M_IT; ++it) {
+      const int gi = ptid + M_PT * it, hp = gi >> 2;
+      const int py = hp / M_COLS, px = hp - py * M_COLS;
+      g_pix[it] = py * W + px;
+      g_yx[it] = gi < M_G ? (py << 8) | px : -1;             // past the image: never loaded, never committed
+    }
+    const int q16 = (ptid & 3) * 16;
+    const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, groups * nchunk * M_WSLAB, 0x00020000);
+    float4 rin[2][M_IT];
+
+    // cursors over the flat step sequence: one for the input requests, one for the weight copies
+    int rq_i = 0, rq_ch = 0, dm_i = 0, dm_ch = 0;
+    WsmItem rq = decode(0), dm = rq;
+    // Past the last step the cursors stay on it: the few look-ahead requests / copies beyond the end of the sequence
+    // re-read the last step's operands into stages nobody multiplies (so every step issues the same number of
+    // vector-memory operations — the counted wait below — and no load ever leaves the tensors)
+    auto request = [&](auto set_c) {                 // loads of the step under the request cursor, then advance it
+      constexpr int RS = decltype(set_c)::value;
+      const bool first = rq_ch * 16 < c0;
+      const ConvSrc& src = first ? a.in0 : a.in1;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(src.p + (size_t)rq.b * src.bs + src.o), 0, (int)((src.bs - src.o) * 4), 0x00020000);
+      const int ps = first ? ps0 : ps1;
+      const int so = (first ? rq_ch * 16 : rq_ch * 16 - c0) * 4 + q16;
+      const int y0 = rq.y0 - 1, x0 = rq.x0 - 1;
+      const int pix0 = y0 * W + x0;
+#pragma unroll
+      for (int it = 0; it < M_IT; ++it) {
+        const int gy = y0 + (g_yx[it] >> 8), gx = x0 + (g_yx[it] & 255);
+        const bool ok = g_yx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int o = (ok && !KP2D_DBG_ON(32)) ? (pix0 + g_pix[it]) * ps + so : OOB;      // (timing ablations: conv_common.h)
+        rin[RS][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+      }
+      if (rq_ch + 1 < nchunk) ++rq_ch;
+      else if (rq_i + 1 < n_my) { rq_ch = 0; rq = decode(++rq_i); }
+    };
+    auto commit = [&](int stage, auto set_c) {       // registers -> hi / lo halves -> image of `stage`
+      constexpr int RS = decltype(set_c)::value;
+#pragma unroll
+      for (int it = 0; it < M_IT; ++it) {
+        if (g_yx[it] < 0 || KP2D_DBG_ON(2)) continue;
+        const int py = g_yx[it] >> 8, px = g_yx[it] & 255;
+        const int lb = stage * M_STAGE + (py * M_PITCH + px) * M_PXB + (ptid & 3) * 8;
+        const float4 v = rin[RS][it];
+        f16x2 h0, h1, l0, l1;
+        split2(v.x, v.y, h0, l0);
+        split2(v.z, v.w, h1, l1);
+        *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<f16x4*>(sm + M_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+    };
+    // weight slab of the step under the copy cursor -> stage: piece p = pw + 4 j covers LDS bytes [1024 p, 1024 p + 1024)
+    // of [wh plane | wl plane], each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row
+    auto copy_w = [&](int stage) {
+      const int sbase = (dm.g * nchunk + dm_ch) * M_WSLAB;
+#pragma unroll
+      for (int j = 0; j < M_PW; ++j) {
+        const int pc = pw + 4 * j;
+        const int o = 1024 * pc + 16 * lane;
+        const int plane = o >= M_WL ? 1 : 0, o2 = o - plane * M_WL;
+        const int voff = KP2D_DBG_ON(16) ? OOB : (o2 >> 5) * 64 + plane * 32 + ((o2 >> 4) & 1) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + stage * M_STAGE + M_IMG + 1024 * pc),
+                                                 16, voff, sbase, 0, 0);
+      }
+      if (dm_ch + 1 < nchunk) ++dm_ch;
+      else if (dm_i + 1 < n_my) { dm_ch = 0; dm = decode(++dm_i); }
+      __builtin_amdgcn_sched_barrier(0);             // the counted wait (WAIT_W) needs the copies OLDER than the next request
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // vmcnt(M_IT): everything but the newest M_IT vector-memory operations — the one request issued after a weight copy —
+    // is done, i.e. this wave's pieces of the slab have landed (loads, stores and LDS-DMA count in issue order)
+    constexpr int WAIT_W = (M_IT & 15) | (7 << 4) | (15 << 8) | ((M_IT >> 4) << 14);
+    auto wait_w = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(WAIT_W);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // step k's image travels in register set k & 1 and lands in stage k & 1
+    request(S0{});                                   // step 0
+    request(S1{});                                   // step 1
+    copy_w(0);                                       // weights of step 0
+    commit(0, S0{});
+    request(S0{});                                   // step 2
+    wait_w();
+    __syncthreads();                                 // barrier 0: stage 0 holds step 0
+    for (int s = 0; s < nsteps_p; s += 2) {
+      // during step s (even): stage 1 <- step s + 1; request step s + 3
+      copy_w(1);
+      commit(1, S1{});
+      request(S1{});
+      wait_w();
+      __syncthreads();
+      // during step s + 1: stage 0 <- step s + 2; request step s + 4
+      copy_w(0);
+      commit(0, S0{});
+      request(S0{});
+      wait_w();
+      __syncthreads();
+    }
+    return;
+  }
+
+  // =================================== multiplying waves ===================================
+  // wave (wr, ph) owns tile rows 4 wr .. 4 wr + 3 x columns 16 ph .. 16 ph + 15 = four M-tiles of 2 x 8 pixels, and all
+  // four 16-channel N-tiles.  The second column half's waves take the row groups rotated by two, so the two waves of a
+  // SIMD (w and w + 4) differ in rows AND columns: in ragged tiles the waves that still work spread over all four SIMDs.
+  constexpr int MT = 4, NN = 4, CB = 2;
+  const int lg = lane >> 4, lp = lane & 15;
+  const int ph = wave >> 2, wr = (wave + 2 * ph) & 3;
+  const int a0 = ((wr * 4 + ((lp >> 1) & 1)) * M_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * M_PXB + 16 * (lg & 1);
+  const int a_dx = a0 + (lg >> 1) * M_PXB;                 // second tap one pixel to the right
+  const int a_dy = a0 + (lg >> 1) * M_PITCH * M_PXB;       // second tap one row down
+  const int a_s = a0 + (lg >> 1) * M_LO;                   // single tap: k-groups 2, 3 read the lo plane
+  const int b_s = M_IMG + lp * 32 + 16 * (lg & 1);
+  const int b_p = b_s + (lg >> 1) * M_N * 32;              // second tap = next slot
+  auto tap_off = [](int t) constexpr { return ((t / 3) * M_PITCH + (t % 3)) * M_PXB; };
+  const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
+  const int store = a.store;
+  const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
+
+  f32x4 acc[MT][NN];
+  auto clear = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto multiply = [&](int sb) {                      // sb: byte offset of the step's stage
+#pragma unroll
+    for (int slot = 0; slot < 9; slot += 2) {
+      const int tp = m_slot_tap(slot);
+      const bool single = slot == 8;
+      const bool dy = slot == 4;
+      const int ab = sb + (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(tp);
+      const int bb = sb + (single ? b_s : b_p) + slot * M_N * 32;
+      f16x8 bh[NN], bl[NN];
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        bh[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512);
+        bl[n] = *reinterpret_cast<const f16x8*>(sm + bb + n * 512 + M_WL);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mo = (2 * (m / CB) * M_PITCH + 8 * (m % CB)) * M_PXB;
+        if (single) {
+          const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], x, acc[m][n], 0, 0, 0);
+          }
+        } else {
+          const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
+          const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + M_LO);
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh, acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  // accumulator tile (m, n): lane (lp, lg) holds pixel lp of M-tile m, channels 16 n + 4 lg .. + 3 of the item's group
+  auto finish = [&](const WsmItem& it) {
+    const bool full = store != ST_NHWC_POOL;
+    const bool pooled = store == ST_NHWC_POOL || store == ST_NHWC_BOTH;
+    const int up = store == ST_SHUFFLE ? 2 : 1;
+    const int HH = H * up, WW = W * up;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        a.out0 + (size_t)it.b * HH * WW * a.os0, 0, full ? HH * WW * a.os0 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        a.out1 + (size_t)it.b * Hp * Wp * a.os1, 0, pooled ? Hp * Wp * a.os1 * 4 : 0, 0x00020000);
+    const int cq = a.cout >> 2;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      const int co4 = it.g * M_N + n * 16 + 4 * lg;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sm + M_SS + co4 * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(sm + M_SS + (M_MAXN + co4) * 4);
+      const bool cok = co4 < a.cout;
+      int cbase0, dy2 = 0, dx2 = 0;                   // full-resolution target: channel offset, sub-pixel (shuffle)
+      if (store == ST_SHUFFLE) {
+        const int sub = co4 / cq;
+        cbase0 = a.oo0 + co4 - sub * cq; dy2 = sub >> 1; dx2 = sub & 1;
+      } else {
+        cbase0 = a.oo0 + co4;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = fmaf(acc[m][n][r], sc[r], sh[r]);
+          v[r] = fmaxf(t, t * slope);
+        }
+        const bool pok = cok && y < H && x < W;
+        if (full) {
+          const int o = pok ? (((up * y + dy2) * WW + up * x + dx2) * a.os0 + cbase0) * 4 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, KP2D_DBG_ON(64) ? OOB : o, 0, 0);
+        }
+        if (pooled) {
+          // the 2 x 2 pixel block of a pooled pixel = lanes 4 q .. 4 q + 3: quad max, lane 4 q stores
+          f32x4 p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = v[r];
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, true)));
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, true)));
+            p[r] = t;
+          }
+          const int yp = y >> 1, xp = x >> 1;
+          const bool ok = cok && (lp & 3) == 0 && yp < Hp && xp < Wp;
+          const int o = ok ? ((yp * Wp + xp) * a.os1 + a.oo1 + co4) * 4 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, p), rs1, KP2D_DBG_ON(64) ? OOB : o, 0, 0);
+        }
+      }
+    }
+  };
+
+  int i = 0, ch = 0;
+  WsmItem cur = decode(0);
+  bool busy = cur.y0 + 4 * wr < H && cur.x0 + 16 * ph < W;      // rows / columns wholly outside the map: nothing to do
+  clear();
+  __syncthreads();                                   // barrier 0
+  for (int s = 0; s < nsteps_p; ++s) {
+    if (s < nsteps) {
+      if (busy && !KP2D_DBG_ON(8)) multiply((s & 1) * M_STAGE);
+      if (++ch == nchunk) {
+        if (busy && !KP2D_DBG_ON(1)) { finish(cur); clear(); }
+        ch = 0;
+        if (++i < n_my) {
+          cur = decode(i);
+          busy = cur.y0 + 4 * wr < H && cur.x0 + 16 * ph < W;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// true when the layer can run as the kernel above (launch_conv3x3_f16x3 falls back to the general kernel otherwise)
+static bool wsm_eligible(const ConvArgs& a) {
+  if (a.taps != 9 || a.prec != 1 || a.ng32 || a.npad % M_N != 0 || a.npad > M_MAXN) return false;
+  if (a.store != ST_NHWC && a.store != ST_SHUFFLE && a.store != ST_NHWC_BOTH && a.store != ST_NHWC_POOL) return false;
+  if (a.act > ACT_RELU) return false;
+  if (((a.in0.c | a.cin) & 15) != 0 || a.cin < 32) return false;      // whole 16-channel chunks, never straddling the sources
+  if (a.cout & 3) return false;
+  if (a.store == ST_SHUFFLE && ((a.cout >> 2) & 3)) return false;
+  if (a.W < 32) return false;
+  if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return false;
+  const long ps = a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps;
+  if ((long)a.H * a.W * ps * 4 >= 0x7ffffff0L) return false;
+  const long up = a.store == ST_SHUFFLE ? 4 : 1;
+  if ((long)a.H * a.W * up * a.os0 * 4 >= 0x7ffffff0L) return false;
+  return true;
+}
+
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, long min_items) {
+  if (!wsm_eligible(a0)) return -1000;
+  ConvArgs a = a0;
+  a.tiles_x = (a.W + M_TW - 1) / M_TW;
+  a.tiles_y = (a.H + M_TH - 1) / M_TH;
+  const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
+  const long nitems = ntiles * (a.npad / M_N);
+  if (nitems < min_items || nitems >= (1L << 30)) return -1000;
+  static PerDeviceOnce lds_once;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel))) return e;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int grid = (int)(nitems < cus ? nitems : cus) & ~7;       // a multiple of 8: contiguous runs per XCD
+  if (grid < 8) return -1000;
+  hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles);
+  return (int)hipGetLastError();
+}
+
+}  // namespace kp2d

@@ -142,6 +142,7 @@ struct kp2d_model {
   float* blob = nullptr;
   bool finalized = false;
   int chunk_frames = 0;
+  int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = KP2D_WSM or 256, < 0 = never (conv3x3_wsm.hip)
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
   int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
@@ -637,11 +638,14 @@ struct Plan {
     const bool split = m->precision == KP2D_PREC_F16X3;
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
+    a.wsm_min = m->wsm_min;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     // Small grids (a frame or two at a time): a 64-channel-group launch would leave most CUs idle and each of its
     // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
-    if (split && c.npad >= 64 && m->small_grid_ng32 &&
+    // (a forced warp-specialised form — kp2d_set_option("wsm_min_items"), the parity tests — keeps its 64-channel groups)
+    const bool wsm_forced = m->wsm_min > 0 && (long)((Wc + 31) / 32) * ((Hc + 15) / 16) * B * (c.npad / 64) >= m->wsm_min;
+    if (split && c.npad >= 64 && m->small_grid_ng32 && !wsm_forced &&
         (long)a.tiles_x * a.tiles_y * B * (c.npad / 64) < 256) {
       a.w = m->blob + c.w16n_off;
       a.ng32 = 1;
@@ -683,6 +687,7 @@ struct Plan {
                             : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
     check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
+    if (m->profiling && !dry) m->prof[m->prof_used].kernel += conv3x3_last_variant();      // which tile form ran
     prof_end();
   }
   // KP2DTinyV2's score head (-> 1 channel, sigmoid) and location head (-> 2, tanh): planar outputs, one launch for both
@@ -1460,6 +1465,17 @@ int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_f
   if (!layer || !dst) { m->tap_name.clear(); m->tap_dst = nullptr; m->tap_cap = 0; return KP2D_OK; }
   m->tap_name = layer; m->tap_dst = dst; m->tap_cap = capacity_floats;
   return KP2D_OK;
+}
+
+int kp2d_set_option(kp2d_model* m, const char* key, long value) {
+  if (!m || !key) return fail(KP2D_ERR_ARG, "bad argument");
+  const std::string k = key;
+  if (k == "wsm_min_items") {
+    if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "wsm_min_items out of range");
+    m->wsm_min = (int)value;
+    return KP2D_OK;
+  }
+  return fail(KP2D_ERR_ARG, "unknown option '%s'", key);
 }
 
 int kp2d_set_chunk_frames(kp2d_model* m, int frames) {

@@ -45,6 +45,7 @@ struct ConvArgs {
   int act, store, nsplit;
   int tiles_x, tiles_y;
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
+  int wsm_min;                        // least (tile, group) work items for the warp-specialised multi-chunk form; 0: KP2D_WSM or 256; < 0: never
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
 
@@ -57,11 +58,17 @@ struct Conv1aArgs {                   // backbone.conv1a: NCHW frame in -> NHWC 
 };
 
 int launch_conv3x3(const ConvArgs& a, int kc, hipStream_t s);
+// tile form the calling thread's last launch_conv3x3* call chose ("<2,1,16>", "ws", "wsm", ...; "" for the fp32 / 1x1 kernels):
+// kp2d_profile_get reports it behind the kernel family, so a test can assert WHICH kernel it covered
+const char* conv3x3_last_variant();
+void conv3x3_note_variant(const char* v);
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, int Ws, hipStream_t s);   // frame front-end fused in
 int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s);   // a 1-channel and a 2-channel head, one launch
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
+// conv3x3_wsm.hip: the same layers, 64-channel groups, warp-specialised and persistent; -1000 = not eligible / fewer than min_items work items
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s, long min_items);
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {

@@ -1006,3 +1006,120 @@ def test_inference_uses_the_fused_front_and_matches_the_two_step_path(monkeypatc
     pts_b, feat_b, _ = pipeline.inference(model, frames, (96, 128), nn_thresh=0.3, top_k=200)
     for a, b in zip(pts_a + feat_a, pts_b + feat_b):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the warp-specialised persistent form of the multi-chunk 64-channel-group layers (conv3x3_wsm.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _kernels_that_ran(model, x):
+    """{layer: kernel family + tile form} of one forward, read back through kp2d_profile_get."""
+    import ctypes as C
+    eng = model._engine
+    lib = eng.lib
+    lib.kp2d_set_profiling(eng.handle, 1)
+    with torch.no_grad():
+        model(x)
+    torch.cuda.synchronize()
+    out = {}
+    layer, kern = C.c_char_p(), C.c_char_p()
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.kp2d_profile_count(eng.handle)):
+        lib.kp2d_profile_get(eng.handle, i, C.byref(layer), C.byref(kern), C.byref(ms), C.byref(fl), C.byref(by))
+        out.setdefault(layer.value.decode(), set()).add(kern.value.decode())
+    lib.kp2d_set_profiling(eng.handle, 0)
+    return out
+
+
+def _set_wsm(model, value):
+    eng = model._engine
+    assert eng.lib.kp2d_set_option(eng.handle, b"wsm_min_items", value) == 0
+
+
+@pytest.mark.parametrize("config,v3,ncls,B,H,W", [
+    # 52 x 88 maps: 4 x 3 tiles of 16 x 32, ragged rows (52 = 3.25 x 16) AND columns (88 = 2.75 x 32), 60 work items on a
+    # 56-workgroup grid (four workgroups walk two items: the trip-count edge n_my = 1 | 2); 26 x 44 maps: 2 x 2 tiles, one
+    # and two 64-channel groups (20 / 40 items: grid 16 / 40); conv3b (full + pooled), convs.1 (pooled), the pixel-shuffle
+    # layers and the two-source layers all take the form
+    ("S", False, 28, 5, 104, 176),
+    ("S", True, 19, 3, 104, 176),       # V3 fused heads: other layer set
+    ("N", False, 28, 4, 96, 160),       # 48-channel layers: THREE chunks (odd step counts: the padded step), cout 48 < 64
+    ("S", False, 28, 1, 240, 320),      # one frame: 40 / 12 / 4 items per launch (n_my = 1 everywhere, tiny grids)
+    ("S", False, 28, 9, 64, 96),        # 32 x 48 maps: 2 x 2 tiles with half-empty column blocks, 16 x 24 maps fall back (W < 32)
+])
+def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3, ncls, B, H, W):
+    """Every output of a forward with the multi-chunk 64-channel-group layers on conv3x3_f16x3_wsm_kernel (forced by
+    wsm_min_items = 8) against the same forward on the general kernels (wsm_min_items = -1): same arithmetic in the
+    same order, so the results must be bit-identical; and the profile must say the form ran where it was meant to."""
+    model, _ = product_model(config, v3, ncls)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=21)).to(DEV)
+    with torch.no_grad():
+        model(x[:1])
+        _set_wsm(model, -1)
+        ran_off = _kernels_that_ran(model, x)
+        ref = {k: v.clone() for k, v in model(x).items()}
+        _set_wsm(model, 8)
+        ran_on = _kernels_that_ran(model, x)
+        got = {k: v.clone() for k, v in model(x).items()}
+        _set_wsm(model, 0)
+    assert not any("<wsm>" in k for ks in ran_off.values() for k in ks)
+    wsm_layers = sorted(l for l, ks in ran_on.items() if any("<wsm>" in k for k in ks))
+    # (N: backbone.conv3b is 24 -> 48 channels, not whole 16-channel chunks: it stays on the general kernel)
+    # (64 x 96 frames: only the 32 x 48 maps are wide enough for a 32-pixel tile)
+    want = {"backbone.conv4b", "desc_head.convB"} if H > 64 else {"desc_head.confAa", "seg_head.convs.7"}
+    assert ("backbone.conv3b" in wsm_layers or config == "N") and want <= set(wsm_layers), wsm_layers
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()), wsm_layers)
+
+
+@pytest.mark.parametrize("precision,form", [("f16x3", "default"), ("f16x3", "wsm"), ("fp32", "default")])
+def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(precision, form):
+    """The fast tile forms need big launches (ws >= 1024 tiles, wsm >= 256 items, <1,2,16> >= 1024 wide tiles, flat32 >= 512)
+    and no fixture batch is that large, so they used to be checked only by bit-equality with the general kernel.  Here the
+    two frames of the reference fixture v2_S_240x320 are tiled to the headline batch of 64: the kernels that run are the
+    ones bench.py times, and frames 0 / 1 (and two copies deep in the batch) are compared with the REFERENCE's outputs."""
+    from nano_vs_slam_amd.selectors import select_keypoints
+    meta, z = load_golden("v2_S_240x320")
+    cfg, sd, x2 = golden_inputs(meta)
+    assert meta["B"] == 2
+    model, _ = product_model(meta["config"], meta["v3"], meta["n_classes"], recipe=meta.get("weights", "spread"))
+    model.set_precision(precision)
+    H, W, st = meta["H"], meta["W"], meta["dense_stride"]
+    B = 64
+    x = torch.from_numpy(np.ascontiguousarray(np.tile(x2, (B // 2, 1, 1, 1)))).to(DEV)
+    if precision == "f16x3":
+        with torch.no_grad():
+            model(x[:1])
+        _set_wsm(model, 64 if form == "wsm" else -1)      # (two stream lanes of 32 frames: 128 items at 30 x 40)
+        ran = _kernels_that_ran(model, x)
+        forms = {k for ks in ran.values() for k in ks}
+        assert any("<ws>" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
+        big = ("backbone.conv3b", "backbone.conv4a", "desc_head.confAa", "desc_head.convB", "seg_head.convs.1", "seg_head.convs.3", "seg_head.convs.7")
+        for layer in big:
+            if form == "wsm":
+                assert any("<wsm>" in k for k in ran[layer]), (layer, ran[layer])
+            else:
+                assert any("<2,1,16>" in k or "<2,1,8>" in k for k in ran[layer]), (layer, ran[layer])
+        assert any("<1,2,16>" in k for k in forms) and any("flat32" in k for k in forms), forms
+    with torch.no_grad():
+        out = model(x)
+        post = model.post_processing(out, H, W)
+    for b in (0, 1, 30, 63):
+        r = b & 1
+        f = {k: v[b:b + 1].cpu().numpy() for k, v in out.items()}
+        assert np.max(np.abs(f["score"] - z["fwd_score"][r:r + 1])) < TOL
+        assert np.max(np.abs(f["coord"] - z["fwd_shift"][r:r + 1])) < TOL
+        assert np.max(np.abs(f["vlad"] - z["fwd_vlad"][r:r + 1])) < 1e-5
+        assert np.max(np.abs(f["feat"][:, :, ::st, ::st] - z["fwd_feat"][r:r + 1])) < TOL
+        assert np.max(np.abs(f["seg"][:, :, ::st, ::st] - z["fwd_seg"][r:r + 1])) < TOL
+        assert np.max(np.abs(post["score"][b].cpu().numpy() - z["post_score"][r])) < TOL
+        assert np.max(np.abs(post["feat"][b].cpu().numpy() - z["post_feat"][r])) < TOL
+    ref_scores = z["post_score"].reshape(2, -1)
+    for k in (300, 1000):
+        sel = select_keypoints(post, 0.7, k)
+        for b in (0, 1, 30, 63):
+            r = b & 1
+            ref = z[f"k1_top{k}_idx_{r}"]
+            got = np.sort(sel[b][2].cpu().numpy())
+            kth = ref_scores[r][ref].min() if len(ref) else 0.7
+            bound = 0.7 if len(z[f"keep_idx_{r}"]) <= k else kth
+            _same_set(got, ref, ref_scores[r], bound, label=f"headline-batch[{precision}] K1 top-{k} frame {b}")
