@@ -593,12 +593,9 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   const bool one = a.npad == 32 || a.ng32;
   if (!one) {
     // multi-chunk layers with 64-channel groups on grids that fill the chip: warp-specialised persistent form
-    // (conv3x3_wsm.hip).  KP2D_WSM = least number of (tile, group) work items (256 = one per CU), 0 = never (the default
-    // until the form wins end to end: DESIGN.md section 5, round 4).
-    static const long wsm_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : 0;
-    const long wsm_min = a.wsm_min ? a.wsm_min : wsm_env;
-    if (wsm_min > 0) {
-      const int e = launch_conv3x3_f16x3_wsm(a, s, wsm_min);
+    // (conv3x3_wsm.hip; policy and overrides at its launcher)
+    {
+      const int e = launch_conv3x3_f16x3_wsm(a, s);
       if (e != -1000) { g_variant = "<wsm>"; return e; }
     }
     // map heights that leave the last 16-row tile row at most half full (120 = 7.5 x 16): 8 x 32 tiles, no ragged row

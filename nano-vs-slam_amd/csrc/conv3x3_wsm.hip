@@ -60,6 +60,9 @@ __host__ __device__ constexpr int wsm_padded_steps(int nsteps) { return (nsteps 
 struct WsmItem { int b, y0, x0, g; };
 }  // namespace
 
+// STORE: the layer's store mode (kp2d_kernels.h::Store) as a template parameter — the pooled path's registers and DPP code
+// exist only in the two instantiations that pool
+template <int STORE>
 __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const ConvArgs a, const int nitems, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
@@ -108,16 +111,21 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
 
   if (!consumer) {
     // =================================== staging waves ===================================
-    __builtin_amdgcn_s_setprio(1);                   // their short bursts go ahead of the multiplying waves' issue
+    // The staging waves share their SIMDs with the multiplying waves, whose MFMAs leave about half of the vector issue
+    // slots: every instruction here is issue time taken from, or waited for by, the matrix stream (first form of this
+    // kernel: ~870 instructions per step and s_setprio 1 — the two roles ran one after the other, profiles/r4_wsm_*).
+    // So everything that does not change from step to step lives in per-thread tables, the per-item part (pixel indices
+    // of the halo granules) is computed once per item, and a load is four VALU instructions.
+    if (KP2D_DBG_ON(256)) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - 512, pw = wave - 8;
     // granule gi = ptid + 256 it of a halo image = (halo pixel hp = gi / 4 = (py, px), channels 4 (gi % 4) ...)
-    int g_pix[M_IT], g_yx[M_IT];
+    int g_yx[M_IT], g_lds[M_IT];
 #pragma unroll
     for (int it = 0; it < M_IT; ++it) {
       const int gi = ptid + M_PT * it, hp = gi >> 2;
       const int py = hp / M_COLS, px = hp - py * M_COLS;
-      g_pix[it] = py * W + px;
       g_yx[it] = gi < M_G ? (py << 8) | px : -1;             // past the image: never loaded, never committed
+      g_lds[it] = (py * M_PITCH + px) * M_PXB + (ptid & 3) * 8;
     }
     const int q16 = (ptid & 3) * 16;
     const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;
@@ -125,39 +133,51 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
         const_cast<float*>(a.w), 0, groups * nchunk * M_WSLAB, 0x00020000);
     float4 rin[2][M_IT];
 
-    // cursors over the flat step sequence: one for the input requests, one for the weight copies
-    int rq_i = 0, rq_ch = 0, dm_i = 0, dm_ch = 0;
-    WsmItem rq = decode(0), dm = rq;
-    // Past the last step the cursors stay on it: the few look-ahead requests / copies beyond the end of the sequence
-    // re-read the last step's operands into stages nobody multiplies (so every step issues the same number of
-    // vector-memory operations — the counted wait below — and no load ever leaves the tensors)
+    // cursors over the flat step sequence: one for the input requests, one for the weight copies.  Past the last step
+    // they stay on it: the few look-ahead requests / copies beyond the end re-read the last step's operands into stages
+    // nobody multiplies (every step issues the same number of vector-memory operations — the counted wait below — and
+    // no load ever leaves the tensors)
+    int rq_i = 0, rq_ch = 0, dm_i = 0, dm_ch = 0, dm_g = 0;
+    int rq_b = 0;
+    int pix[M_IT];                                   // pixel index of each granule in the request cursor's item, < 0: zero padding
+    auto enter_item = [&](int i) {                   // request cursor enters item i
+      const WsmItem r = decode(i);
+      rq_b = r.b;
+      const int y0 = r.y0 - 1, x0 = r.x0 - 1;
+#pragma unroll
+      for (int it = 0; it < M_IT; ++it) {
+        const int gy = y0 + (g_yx[it] >> 8), gx = x0 + (g_yx[it] & 255);
+        const bool ok = g_yx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        pix[it] = ok ? gy * W + gx : -1;
+      }
+    };
+    auto group_of = [&](int i) { const int j = i * G + off; return groups == 1 ? 0 : j % groups; };
+    enter_item(0);
+    dm_g = group_of(0);
     auto request = [&](auto set_c) {                 // loads of the step under the request cursor, then advance it
       constexpr int RS = decltype(set_c)::value;
       const bool first = rq_ch * 16 < c0;
       const ConvSrc& src = first ? a.in0 : a.in1;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(src.p + (size_t)rq.b * src.bs + src.o), 0, (int)((src.bs - src.o) * 4), 0x00020000);
+          const_cast<float*>(src.p + (size_t)rq_b * src.bs + src.o), 0, (int)((src.bs - src.o) * 4), 0x00020000);
       const int ps = first ? ps0 : ps1;
       const int so = (first ? rq_ch * 16 : rq_ch * 16 - c0) * 4 + q16;
-      const int y0 = rq.y0 - 1, x0 = rq.x0 - 1;
-      const int pix0 = y0 * W + x0;
 #pragma unroll
       for (int it = 0; it < M_IT; ++it) {
-        const int gy = y0 + (g_yx[it] >> 8), gx = x0 + (g_yx[it] & 255);
-        const bool ok = g_yx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const int o = (ok && !KP2D_DBG_ON(32)) ? (pix0 + g_pix[it]) * ps + so : OOB;      // (timing ablations: conv_common.h)
+        // a negative pixel index ORs the offset up to >= 0x7ffffff0: out of range, the load returns the zero padding
+        int o = (pix[it] * ps + so) | ((pix[it] >> 31) & OOB);
+        if (KP2D_DBG_ON(32)) o = OOB;                // (timing ablations: conv_common.h)
         rin[RS][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
       }
       if (rq_ch + 1 < nchunk) ++rq_ch;
-      else if (rq_i + 1 < n_my) { rq_ch = 0; rq = decode(++rq_i); }
+      else if (rq_i + 1 < n_my) { rq_ch = 0; enter_item(++rq_i); }
     };
     auto commit = [&](int stage, auto set_c) {       // registers -> hi / lo halves -> image of `stage`
       constexpr int RS = decltype(set_c)::value;
 #pragma unroll
       for (int it = 0; it < M_IT; ++it) {
-        if (g_yx[it] < 0 || KP2D_DBG_ON(2)) continue;
-        const int py = g_yx[it] >> 8, px = g_yx[it] & 255;
-        const int lb = stage * M_STAGE + (py * M_PITCH + px) * M_PXB + (ptid & 3) * 8;
+        if ((it == M_IT - 1 && g_yx[it] < 0) || KP2D_DBG_ON(2)) continue;      // (only the last granule can lie past the image)
+        const int lb = stage * M_STAGE + g_lds[it];
         const float4 v = rin[RS][it];
         f16x2 h0, h1, l0, l1;
         split2(v.x, v.y, h0, l0);
@@ -167,20 +187,21 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       }
     };
     // weight slab of the step under the copy cursor -> stage: piece p = pw + 4 j covers LDS bytes [1024 p, 1024 p + 1024)
-    // of [wh plane | wl plane], each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row
+    // of [wh plane | wl plane], each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row: lane l
+    // reads row 32 p' + l / 2 (p' = piece inside its plane), half (l & 1) of the plane's 32 bytes — the lane part is one
+    // register for all pieces, the piece part is scalar (the instruction's soffset)
+    const int w_lane = (lane >> 1) * 64 + (lane & 1) * 16;
     auto copy_w = [&](int stage) {
-      const int sbase = (dm.g * nchunk + dm_ch) * M_WSLAB;
+      const int sbase = (dm_g * nchunk + dm_ch) * M_WSLAB;
 #pragma unroll
       for (int j = 0; j < M_PW; ++j) {
         const int pc = pw + 4 * j;
-        const int o = 1024 * pc + 16 * lane;
-        const int plane = o >= M_WL ? 1 : 0, o2 = o - plane * M_WL;
-        const int voff = KP2D_DBG_ON(16) ? OOB : (o2 >> 5) * 64 + plane * 32 + ((o2 >> 4) & 1) * 16;
+        const int plane = pc >= M_WL / 1024 ? 1 : 0, pp = pc - plane * (M_WL / 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + stage * M_STAGE + M_IMG + 1024 * pc),
-                                                 16, voff, sbase, 0, 0);
+                                                 16, KP2D_DBG_ON(16) ? OOB : w_lane, sbase + 2048 * pp + 32 * plane, 0, 0);
       }
       if (dm_ch + 1 < nchunk) ++dm_ch;
-      else if (dm_i + 1 < n_my) { dm_ch = 0; dm = decode(++dm_i); }
+      else if (dm_i + 1 < n_my) { dm_ch = 0; dm_g = group_of(++dm_i); }
       __builtin_amdgcn_sched_barrier(0);             // the counted wait (WAIT_W) needs the copies OLDER than the next request
     };
     using S0 = std::integral_constant<int, 0>;
@@ -190,7 +211,8 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     constexpr int WAIT_W = (M_IT & 15) | (7 << 4) | (15 << 8) | ((M_IT >> 4) << 14);
     auto wait_w = [&]() {
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(WAIT_W);
+      if (KP2D_DBG_ON(512)) __builtin_amdgcn_s_waitcnt(0x0f70);      // (diagnostic: drain everything)
+      else __builtin_amdgcn_s_waitcnt(WAIT_W);
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -234,8 +256,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   const int b_p = b_s + (lg >> 1) * M_N * 32;              // second tap = next slot
   auto tap_off = [](int t) constexpr { return ((t / 3) * M_PITCH + (t % 3)) * M_PXB; };
   const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
-  const int store = a.store;
-  const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
+  constexpr int store = STORE;
 
   f32x4 acc[MT][NN];
   auto clear = [&]() {
@@ -281,59 +302,80 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       }
     }
   };
-  // accumulator tile (m, n): lane (lp, lg) holds pixel lp of M-tile m, channels 16 n + 4 lg .. + 3 of the item's group
+  // ---- epilogue.  Accumulator tile (m, n): lane (lp, lg) holds pixel lp of M-tile m, channels 16 n + 4 lg .. + 3 of the
+  // item's group.  A lane's byte offset per M-tile (pixel part, padding lanes ORed out of range) is computed once per
+  // item; the channel / sub-pixel part of an N-tile is wave-uniform: one scalar added per store.
+  // (NOT in the store's soffset operand: with an SGPR there hipcc pads no wait state between a 16-byte buffer store and
+  // the next VALU write of its data registers — LLVM's rule says that form has no hazard — and on gfx950 the first
+  // dword of lanes 12-15 of every row of 16 was then, now and again, the NEXT tile's value: profiles/r4_wsm_store_hazard.txt)
+  // (Measured and rejected, profiles/r4_wsm_split_epilogue.txt: an item's stores spread over its last chunk and the next
+  // item's first — N-tile pairs finished one after the other, the finished pair stored in pieces between the other
+  // pair's slot groups.  With separate bodies for plain chunks the register allocator no longer kept the MFMAs in place
+  // and spilled 40-80 accumulator registers; as ONE body with always-running pieces the matrix phase became issue-bound
+  // (2.36 ms for the layers that take 1.96 ms this way), with branch-skipped pieces 2.12 ms.) ----
+  constexpr bool full = store != ST_NHWC_POOL;
+  constexpr bool pooled = store == ST_NHWC_POOL || store == ST_NHWC_BOTH;
+  constexpr int up = store == ST_SHUFFLE ? 2 : 1;
+  const int HH = H * up, WW = W * up, Hp = H >> 1, Wp = W >> 1;
+  const int cq = a.cout >> 2;
   auto finish = [&](const WsmItem& it) {
-    const bool full = store != ST_NHWC_POOL;
-    const bool pooled = store == ST_NHWC_POOL || store == ST_NHWC_BOTH;
-    const int up = store == ST_SHUFFLE ? 2 : 1;
-    const int HH = H * up, WW = W * up;
-    const int Hp = H >> 1, Wp = W >> 1;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         a.out0 + (size_t)it.b * HH * WW * a.os0, 0, full ? HH * WW * a.os0 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         a.out1 + (size_t)it.b * Hp * Wp * a.os1, 0, pooled ? Hp * Wp * a.os1 * 4 : 0, 0x00020000);
-    const int cq = a.cout >> 2;
+    const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
+    int vo[MT], vp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
+      const int inv = (y < H && x < W) ? 0 : OOB;
+      vo[m] = full ? ((up * y * WW + up * x) * a.os0 + 4 * lg) * 4 | inv : 0;
+      const int yp = y >> 1, xp = x >> 1;
+      const int invp = ((lp & 3) == 0 && yp < Hp && xp < Wp) ? 0 : OOB;      // lane 4 q stores the quad's maximum
+      vp[m] = pooled ? ((yp * Wp + xp) * a.os1 + 4 * lg) * 4 | invp : 0;
+    }
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
-      const int co4 = it.g * M_N + n * 16 + 4 * lg;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(sm + M_SS + co4 * 4);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(sm + M_SS + (M_MAXN + co4) * 4);
-      const bool cok = co4 < a.cout;
-      int cbase0, dy2 = 0, dx2 = 0;                   // full-resolution target: channel offset, sub-pixel (shuffle)
+      const int cn = it.g * M_N + n * 16;                       // first channel of the N-tile (wave-uniform)
+      if (cn >= a.cout) continue;                               // a padded N-tile (cout = 48: the fourth)
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sm + M_SS + (cn + 4 * lg) * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(sm + M_SS + (M_MAXN + cn + 4 * lg) * 4);
+      const int cinv = cn + 4 * lg < a.cout ? 0 : OOB;          // channels past cout (a multiple of 4)
+      int s0;                                                   // scalar byte offset: channel (and sub-pixel of PixelShuffle)
       if (store == ST_SHUFFLE) {
-        const int sub = co4 / cq;
-        cbase0 = a.oo0 + co4 - sub * cq; dy2 = sub >> 1; dx2 = sub & 1;
+        const int sub = cn / cq;
+        s0 = (((sub >> 1) * WW + (sub & 1)) * a.os0 + a.oo0 + cn - sub * cq) * 4;
       } else {
-        cbase0 = a.oo0 + co4;
+        s0 = (a.oo0 + cn) * 4;
       }
+      const int s1 = (a.oo1 + cn) * 4;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t = fmaf(acc[m][n][r], sc[r], sh[r]);
           v[r] = fmaxf(t, t * slope);
         }
-        const bool pok = cok && y < H && x < W;
-        if (full) {
-          const int o = pok ? (((up * y + dy2) * WW + up * x + dx2) * a.os0 + cbase0) * 4 : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, KP2D_DBG_ON(64) ? OOB : o, 0, 0);
-        }
+        if (full)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, KP2D_DBG_ON(64) ? OOB : ((vo[m] + s0) | cinv), 0, 0);
         if (pooled) {
-          // the 2 x 2 pixel block of a pooled pixel = lanes 4 q .. 4 q + 3: quad max, lane 4 q stores
+          // the 2 x 2 pixel block of a pooled pixel = lanes 4 q .. 4 q + 3: maximum over the quad in two DPP steps per
+          // value.  v_max_f32_dpp by hand (the builtin form costs a v_mov_dpp + two v_max per step); the s_nop covers
+          // "VALU write -> DPP read" for the inputs, the four independent instructions in between cover it for stage two
           f32x4 p;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = v[r];
-            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, true)));
-            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, true)));
-            p[r] = t;
-          }
-          const int yp = y >> 1, xp = x >> 1;
-          const bool ok = cok && (lp & 3) == 0 && yp < Hp && xp < Wp;
-          const int o = ok ? ((yp * Wp + xp) * a.os1 + a.oo1 + co4) * 4 : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, p), rs1, KP2D_DBG_ON(64) ? OOB : o, 0, 0);
+          asm("s_nop 1\n\t"
+              "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+              "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+              "s_nop 1"
+              : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, p), rs1, KP2D_DBG_ON(64) ? OOB : ((vp[m] + s1) | cinv), 0, 0);
         }
       }
     }
@@ -367,7 +409,7 @@ static bool wsm_eligible(const ConvArgs& a) {
   if (a.act > ACT_RELU) return false;
   if (((a.in0.c | a.cin) & 15) != 0 || a.cin < 32) return false;      // whole 16-channel chunks, never straddling the sources
   if (a.cout & 3) return false;
-  if (a.store == ST_SHUFFLE && ((a.cout >> 2) & 3)) return false;
+  if (a.store == ST_SHUFFLE && ((a.cout >> 2) & 15)) return false;      // a 16-channel N-tile is one sub-pixel
   if (a.W < 32) return false;
   if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return false;
   const long ps = a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps;
@@ -377,21 +419,43 @@ static bool wsm_eligible(const ConvArgs& a) {
   return true;
 }
 
-int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, long min_items) {
+// Policy.  A workgroup of this form fills its CU's LDS, so launches of two stream lanes can only run side by side on
+// DISJOINT CUs: with L lanes a launch takes at most CUs / L workgroups (kp2d_api.cpp passes L; a profiling forward runs
+// one lane and takes the whole chip).  The form is used when a launch has at least one work item per workgroup of
+// that grid.  Overrides: ConvArgs::wsm_min / wsm_grid (kp2d_set_option), else KP2D_WSM (0 = never, N = least items) and
+// KP2D_WSM_GRID.
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s) {
+  static const long min_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : -1;      // -1: automatic
+  static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;
+  if (a0.wsm_min < 0 || (a0.wsm_min == 0 && min_env == 0)) return -1000;
   if (!wsm_eligible(a0)) return -1000;
   ConvArgs a = a0;
   a.tiles_x = (a.W + M_TW - 1) / M_TW;
   a.tiles_y = (a.H + M_TH - 1) / M_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   const long nitems = ntiles * (a.npad / M_N);
-  if (nitems < min_items || nitems >= (1L << 30)) return -1000;
-  static PerDeviceOnce lds_once;
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel))) return e;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int grid = (int)(nitems < cus ? nitems : cus) & ~7;       // a multiple of 8: contiguous runs per XCD
+  const int lanes = a.wsm_lanes > 1 ? a.wsm_lanes : 1;
+  int cap = a.wsm_grid > 0 ? a.wsm_grid : (grid_env > 0 ? grid_env : cus / lanes);
+  if (cap > cus) cap = cus;
+  cap &= ~7;                                                   // a multiple of 8: contiguous runs per XCD
+  const long min_items = a.wsm_min > 0 ? a.wsm_min : (min_env > 0 ? min_env : cap);
+  if (cap < 8 || nitems < min_items || nitems >= (1L << 30)) return -1000;
+  const int grid = (int)(nitems < cap ? nitems : cap) & ~7;
   if (grid < 8) return -1000;
-  hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles);
+  const void* fn = a.store == ST_NHWC ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC>)
+                 : a.store == ST_SHUFFLE ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_SHUFFLE>)
+                 : a.store == ST_NHWC_BOTH ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC_BOTH>)
+                                           : reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC_POOL>);
+  static PerDeviceOnce lds_once[4];
+  if (int e = lds_opt_in(lds_once[a.store == ST_NHWC ? 0 : a.store == ST_SHUFFLE ? 1 : a.store == ST_NHWC_BOTH ? 2 : 3], fn)) return e;
+  switch (a.store) {
+    case ST_NHWC: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
+    case ST_SHUFFLE: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_SHUFFLE>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
+    case ST_NHWC_BOTH: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC_BOTH>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
+    default: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC_POOL>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
+  }
   return (int)hipGetLastError();
 }
 

@@ -142,7 +142,8 @@ struct kp2d_model {
   float* blob = nullptr;
   bool finalized = false;
   int chunk_frames = 0;
-  int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = KP2D_WSM or 256, < 0 = never (conv3x3_wsm.hip)
+  int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
+  int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
   int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
@@ -574,6 +575,7 @@ struct Plan {
   bool dry = false;       // only size the arena
   int B, H, W;
   int b0 = 0;             // first frame of this sub-batch in the caller's batch
+  int nlanes = 1;         // stream lanes of this forward (conv3x3_wsm.hip sizes its grid by it)
   int rc = KP2D_OK;
 
   // kp2d_set_tap: copy activation `a` (this sub-batch's frames) to the caller's planar [B,C,H,W] buffer
@@ -639,6 +641,8 @@ struct Plan {
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
     a.wsm_min = m->wsm_min;
+    a.wsm_grid = m->wsm_grid;
+    a.wsm_lanes = nlanes;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     // Small grids (a frame or two at a time): a 64-channel-group launch would leave most CUs idle and each of its
@@ -1287,6 +1291,7 @@ static int forward_impl(kp2d_model* m, const float* x, const uint8_t* frames, in
     P.m = m; P.stream = lane == 0 ? caller : m->lane_streams[lane - 1];
     P.ws = (char*)workspace + (size_t)lane * per; P.dry = false;
     P.B = std::min(chunk, B - b0); P.H = H; P.W = W; P.b0 = b0;
+    P.nlanes = std::min(nl, (B + chunk - 1) / chunk);
     P.arena.reset(per);
     FwdOut o{};
     o.x = x ? x + (size_t)b0 * g.in_channels * H * W : nullptr;
@@ -1473,6 +1478,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "wsm_min_items") {
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "wsm_min_items out of range");
     m->wsm_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "wsm_grid") {
+    if (value < 0 || value > 65536) return fail(KP2D_ERR_ARG, "wsm_grid out of range");
+    m->wsm_grid = (int)value;
     return KP2D_OK;
   }
   return fail(KP2D_ERR_ARG, "unknown option '%s'", key);

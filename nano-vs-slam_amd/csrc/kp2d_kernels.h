@@ -45,7 +45,9 @@ struct ConvArgs {
   int act, store, nsplit;
   int tiles_x, tiles_y;
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
-  int wsm_min;                        // least (tile, group) work items for the warp-specialised multi-chunk form; 0: KP2D_WSM or 256; < 0: never
+  int wsm_min;                        // least (tile, group) work items for the warp-specialised multi-chunk form; 0: automatic (KP2D_WSM, else one per workgroup); < 0: never
+  int wsm_lanes;                      // stream lanes launching side by side (the form takes CUs / lanes workgroups)
+  int wsm_grid;                       // most workgroups of that form per launch; 0: KP2D_WSM_GRID or one per CU
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
 
@@ -68,7 +70,7 @@ int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s); 
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 // conv3x3_wsm.hip: the same layers, 64-channel groups, warp-specialised and persistent; -1000 = not eligible / fewer than min_items work items
-int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s, long min_items);
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s);
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {
