@@ -1103,10 +1103,11 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
         assert any("<1,2,16>" in k for k in forms) and any("flat32" in k for k in forms), forms
     with torch.no_grad():
         out = model(x)
+        fwd = {b: {k: v[b:b + 1].cpu().numpy() for k, v in out.items()} for b in (0, 1, 30, 63)}      # (post_processing works in place)
         post = model.post_processing(out, H, W)
     for b in (0, 1, 30, 63):
         r = b & 1
-        f = {k: v[b:b + 1].cpu().numpy() for k, v in out.items()}
+        f = fwd[b]
         assert np.max(np.abs(f["score"] - z["fwd_score"][r:r + 1])) < TOL
         assert np.max(np.abs(f["coord"] - z["fwd_shift"][r:r + 1])) < TOL
         assert np.max(np.abs(f["vlad"] - z["fwd_vlad"][r:r + 1])) < 1e-5
