@@ -154,14 +154,38 @@ int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int 
 
 /* replaces: BfFeatureMatcher.match = cv2.BFMatcher(NORM_L2).knnMatch(k=2) + goodMatchesOneToOne
  * (src/visual_odometry/feature_matcher.py:89-98, :179-209), batched over B frame pairs, on device.
- *   d0 [B,max0,C] query descriptors, n0 [B] valid rows; d1 [B,max1,C] train descriptors, n1 [B]; C in {32,64}
+ *   d0 [B,max0,C] query descriptors, n0 [B] valid rows; d1 [B,max1,C] train descriptors, n1 [B]; C in {32,64,128}
  *   nn_idx / nn_dist / nn_dist2 [B,max0]  nearest train row, its L2 distance, second-nearest distance
+ *     (nn_idx alone = cv2.BFMatcher(NORM_L2, crossCheck=False).match, src/evaluation/descriptor.py:132-134)
  *   match_q [B,max1]  the query kept for each train row after ratio test + one-to-one filtering (-1: none)
  *   match_d [B,max1]  its distance
  *   scratch: B*max1*8 bytes of device memory */
 int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
                            int max1, int C, float ratio, int32_t* nn_idx, float* nn_dist, float* nn_dist2,
                            int32_t* match_q, float* match_d, void* scratch, void* stream);
+/* The same with the matcher variants of the reference's callers:
+ *   cls0 [B,max0] / cls1 [B,max1] (both or neither): per-row class ids — a query only sees train rows of its own class.
+ *     Replaces VisualOdometry.match_semantic (src/visual_odometry/visual_odometry.py:347-380: one BF match per class
+ *     id, 28 of them per frame) with ONE launch.  A query whose class has fewer than two train rows gets no match (the
+ *     reference's knnMatch(k=2) has no second neighbour there and match_semantic skips the class).  NOTE: as shipped,
+ *     the reference's match_semantic unpacks two values from a matcher that returns three, so every class lands in its
+ *     bare `except` and it returns no matches at all; this implements what the loop is written to do.
+ *   flags & KP2D_MATCH_MUTUAL: match_q[t] = q iff t is q's nearest train row AND q is t's nearest query; no ratio test
+ *     (cv2.BFMatcher(NORM_L2, crossCheck=True).match, src/evaluation/descriptor.py:221-222).
+ *   scratch: kp2d_match_scratch_bytes(B, max0, max1) bytes, 8-byte aligned (B*max1*16 is the least accepted; the rest
+ *     lets a search with few pairs spread one query's train rows over several workgroups). */
+#define KP2D_MATCH_MUTUAL 1u
+size_t kp2d_match_scratch_bytes(int B, int max0, int max1);
+int kp2d_match_descriptors_ex(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
+                              int max1, int C, float ratio, const int32_t* cls0, const int32_t* cls1, uint32_t flags,
+                              int32_t* nn_idx, float* nn_dist, float* nn_dist2, int32_t* match_q, float* match_d,
+                              void* scratch, size_t scratch_bytes, void* stream);
+/* The matched rows of every pair as compact lists in train order (what the VO loop takes to the host instead of every
+ * keypoint and descriptor: visual_odometry.py:270-284 kps0 = prev_keypoints[idxs0], kps1 = kps_cur[idxs1]):
+ *   pairs [B,max1,4] (x0, y0, x1, y1) from pts0 [B,max0,2] / pts1 [B,max1,2]; idx [B,max1,2] (query row, train row);
+ *   dist [B,max1]; count [B].  pairs / idx / dist may each be NULL. */
+int kp2d_match_pairs(const int32_t* match_q, const float* match_d, const float* pts0, const float* pts1, int B, int max0,
+                     int max1, float* pairs, int32_t* idx, float* dist, int32_t* count, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* when on, every kernel launch of kp2d_forward is bracketed by HIP events on the caller's stream */

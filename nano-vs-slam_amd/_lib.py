@@ -88,6 +88,10 @@ SIGNATURES = {
     "kp2d_select_keypoints": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P]),
     "kp2d_preprocess": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "kp2d_match_descriptors": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "kp2d_match_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "kp2d_match_descriptors_ex": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_uint32,
+                                            _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kp2d_match_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "kp2d_set_profiling": (C.c_int, [_P, C.c_int]),
     "kp2d_profile_count": (C.c_int, [_P]),
     "kp2d_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _F,

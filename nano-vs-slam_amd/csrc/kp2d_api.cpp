@@ -1414,6 +1414,52 @@ int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int 
   return KP2D_OK;
 }
 
+// scratch layout of the matcher: [train_best u64 B*max1][rnn_idx i32 B*max1][rnn_dist f32 B*max1][partials]
+static constexpr int kMatchSlices = 16;
+static bool match_wants_slices(int B, int max0, int max1) {
+  // few pairs: the train range of a query is split over several workgroups (match.hip knn2()); needs partial arrays
+  return (long)((std::min(max0, max1) + 63) / 64) * B < 512;
+}
+size_t kp2d_match_scratch_bytes(int B, int max0, int max1) {
+  if (B < 1 || max0 < 1 || max1 < 1) return 0;
+  size_t n = (size_t)B * max1 * 16;
+  if (match_wants_slices(B, max0, max1)) n += (size_t)kMatchSlices * B * std::max(max0, max1) * 12;
+  return (n + 255) & ~(size_t)255;
+}
+
+int kp2d_match_descriptors_ex(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
+                              int max1, int C, float ratio, const int32_t* cls0, const int32_t* cls1, uint32_t flags,
+                              int32_t* nn_idx, float* nn_dist, float* nn_dist2, int32_t* match_q, float* match_d,
+                              void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d0 || !n0 || !d1 || !n1 || !nn_idx || !nn_dist || !nn_dist2 || !match_q || !match_d || !scratch)
+    return fail(KP2D_ERR_ARG, "null argument");
+  if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
+  if ((cls0 == nullptr) != (cls1 == nullptr)) return fail(KP2D_ERR_ARG, "class ids must be given for both sides or neither");
+  if (flags & ~(uint32_t)KP2D_MATCH_MUTUAL) return fail(KP2D_ERR_ARG, "unknown match flags 0x%x", flags);
+  if (scratch_bytes < (size_t)B * max1 * 16) return fail(KP2D_ERR_WORKSPACE, "match scratch %zu B < required %zu B (kp2d_match_scratch_bytes)", scratch_bytes, kp2d_match_scratch_bytes(B, max0, max1));
+  if ((uintptr_t)scratch % 8) return fail(KP2D_ERR_WORKSPACE, "match scratch must be 8-byte aligned");
+  DeviceGuard guard(d0, (hipStream_t)stream);
+  MatchArgs a{d0, d1, n0, n1, B, max0, max1, C, ratio, nn_idx, nn_dist, nn_dist2,
+              reinterpret_cast<unsigned long long*>(scratch), match_q, match_d};
+  a.cls0 = cls0; a.cls1 = cls1;
+  a.mutual = (flags & KP2D_MATCH_MUTUAL) ? 1 : 0;
+  char* p = reinterpret_cast<char*>(scratch) + (size_t)B * max1 * 8;
+  a.rnn_idx = reinterpret_cast<int32_t*>(p); p += (size_t)B * max1 * 4;
+  a.rnn_dist = reinterpret_cast<float*>(p); p += (size_t)B * max1 * 4;
+  const size_t left = scratch_bytes - (size_t)B * max1 * 16;
+  const size_t per_slice = (size_t)B * std::max(max0, max1) * 12;
+  if (match_wants_slices(B, max0, max1) && left >= 2 * per_slice) {
+    a.part_slices = (int)std::min<size_t>(kMatchSlices, left / per_slice);
+    const size_t n = (size_t)a.part_slices * B * std::max(max0, max1);
+    a.part_idx = reinterpret_cast<int32_t*>(p);
+    a.part_d = reinterpret_cast<float*>(p + n * 4);
+    a.part_d2 = reinterpret_cast<float*>(p + n * 8);
+  }
+  int e = launch_match(a, (hipStream_t)stream);
+  if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "match kernels: %d (descriptor width %d)", e, C);
+  return KP2D_OK;
+}
+
 int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, const int32_t* n1, int B, int max0,
                            int max1, int C, float ratio, int32_t* nn_idx, float* nn_dist, float* nn_dist2,
                            int32_t* match_q, float* match_d, void* scratch, void* stream) {
@@ -1425,6 +1471,17 @@ int kp2d_match_descriptors(const float* d0, const int32_t* n0, const float* d1, 
               reinterpret_cast<unsigned long long*>(scratch), match_q, match_d};
   int e = launch_match(a, (hipStream_t)stream);
   if (e) return fail(e < 0 ? KP2D_ERR_UNSUPPORTED : KP2D_ERR_HIP, "match kernels: %d (descriptor width %d)", e, C);
+  return KP2D_OK;
+}
+
+int kp2d_match_pairs(const int32_t* match_q, const float* match_d, const float* pts0, const float* pts1, int B, int max0,
+                     int max1, float* pairs, int32_t* idx, float* dist, int32_t* count, void* stream) {
+  if (!match_q || !count || (dist && !match_d) || (pairs && (!pts0 || !pts1))) return fail(KP2D_ERR_ARG, "null argument");
+  if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
+  DeviceGuard guard(match_q, (hipStream_t)stream);
+  PairsArgs a{match_q, match_d, pts0, pts1, B, max0, max1, pairs, idx, dist, count};
+  int e = launch_match_pairs(a, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "match pairs kernel: %d", e);
   return KP2D_OK;
 }
 

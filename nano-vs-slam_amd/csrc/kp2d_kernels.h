@@ -213,7 +213,23 @@ struct MatchArgs {
   int32_t* nn_idx; float* nn_dist; float* nn_dist2;   // [B][max0] k=2 neighbours of every query
   unsigned long long* train_best;                      // [B][max1] scratch: (distance bits << 32 | query)
   int32_t* match_q; float* match_d;                    // [B][max1] query matched to each train row (-1: none)
+  // optional (kp2d_match_descriptors_ex):
+  const int32_t* cls0 = nullptr; const int32_t* cls1 = nullptr;   // [B][max0] / [B][max1] class ids: a query sees its own class only
+  int mutual = 0;                                      // 1: mutual nearest neighbours instead of ratio test + one-to-one
+  int32_t* rnn_idx = nullptr; float* rnn_dist = nullptr;          // [B][max1] nearest query of every train row (mutual)
+  int32_t* part_idx = nullptr; float* part_d = nullptr; float* part_d2 = nullptr;   // [slices][B][max(max0,max1)] partial results
+  int part_slices = 0;                                 // train-range slices the partial arrays can hold (few pairs: more workgroups)
 };
+struct PairsArgs {       // compaction of the matched rows of every pair (train order)
+  const int32_t* match_q; const float* match_d;        // [B][max1]
+  const float* pts0; const float* pts1;                // [B][max0][2] / [B][max1][2] keypoints (x, y); may be null with pairs
+  int B, max0, max1;
+  float* pairs;          // [B][max1][4]  x0, y0, x1, y1 of match i (null: skip)
+  int32_t* idx;          // [B][max1][2]  (query row, train row) (null: skip)
+  float* dist;           // [B][max1]     distance (null: skip)
+  int32_t* count;        // [B]
+};
+int launch_match_pairs(const PairsArgs& a, hipStream_t s);
 int launch_match(const MatchArgs& a, hipStream_t s);
 
 // ---- small layout / elementwise kernels -----------------------------------------------------

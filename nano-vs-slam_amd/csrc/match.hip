@@ -1,10 +1,18 @@
 // Brute-force descriptor matching on the device — the step right after the kp2dtiny path in the VO pipeline
-// (SURVEY.md §8f rank 1).  Replaces BfFeatureMatcher.match = cv2.BFMatcher(NORM_L2).knnMatch(des1, des2, k=2)
-// followed by goodMatchesOneToOne (src/visual_odometry/feature_matcher.py:89-98, :179-209):
+// (SURVEY.md §8f rank 1).  Replaces
+//   * BfFeatureMatcher.match = cv2.BFMatcher(NORM_L2).knnMatch(des1, des2, k=2) followed by goodMatchesOneToOne
+//     (src/visual_odometry/feature_matcher.py:89-98, :179-209) — the VO loop's matcher (visual_odometry.py:270-284);
+//   * the same per semantic class (visual_odometry.py:347-380 match_semantic: one BF match per class id) as ONE launch
+//     with per-row class ids: a query only sees train rows of its own class;
+//   * cv2.BFMatcher(NORM_L2, crossCheck=False).match = plain nearest neighbour (src/evaluation/descriptor.py:132-134:
+//     nn_idx) and crossCheck=True = mutual nearest neighbours (descriptor.py:221-222).
+// Kernels:
 //   knn2_kernel     for every query descriptor the nearest and second-nearest train descriptor,
 //                   distance = sqrt(sum (a-b)^2) in fp32 (OpenCV's L2 norm), lowest index wins ties
-//   assign_kernel   ratio test  d1 <= ratio * d2, then one-to-one: each train index keeps the query with the
+//   assign / emit   ratio test  d1 <= ratio * d2, then one-to-one: each train index keeps the query with the
 //                   smallest distance (first query wins ties) via a 64-bit atomicMin on (distance bits, query)
+//   mutual_kernel   train row t keeps query q = its nearest query iff q's nearest train row is t
+//   pairs_kernel    compacts the matched rows of a pair into (x0, y0, x1, y1) / (q, t) / distance lists (train order)
 // Batched over B frame pairs with per-pair descriptor counts, so the per-frame D2H copy + CPU matcher of the
 // reference disappears.  HBM-light (descriptors are tiny); bound by VALU: n0*n1*C*3 ops per pair.
 #include "kp2d_kernels.h"
@@ -12,39 +20,69 @@
 namespace kp2d {
 
 constexpr int MQ = 64;    // queries per workgroup (4 threads each)
-constexpr int MT = 128;   // train descriptors per LDS tile
+// train descriptors per LDS tile; rows are padded by 4 floats: the four rows a wave reads together (one per `part`) then
+// sit on different banks (unpadded 128- / 512-byte rows: 2- / 4-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// 0.49 at C = 32 and 0.74 at C = 128, profiles/r4_match_pmc_summary.txt)
+__host__ __device__ constexpr int mt_rows(int C) { return C >= 128 ? 64 : 128; }
 
-template <int C>
-__global__ __launch_bounds__(256) void knn2_kernel(const MatchArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_t[MT * C];
+// d0 / n0 / c0: queries, d1 / n1 / c1: train rows (the reverse pass of the mutual mode swaps them).
+// MASKED: rows carry class ids; a (query, train) pair of different classes does not exist for the search.
+// Train rows of a query are split over gridDim.z slices (single pairs of thousands of rows would otherwise be a
+// handful of long workgroups on a 256-CU chip); slice z writes its (best, second, index) to partial arrays that
+// knn2_merge_kernel combines — for gridDim.z == 1 the results go straight out.
+template <int C, bool MASKED>
+__global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
+                                                   const int32_t* __restrict__ n0p, const int32_t* __restrict__ n1p,
+                                                   const int32_t* __restrict__ c0, const int32_t* __restrict__ c1,
+                                                   int max0, int max1, int32_t* __restrict__ nn_idx,
+                                                   float* __restrict__ nn_dist, float* __restrict__ nn_dist2,
+                                                   unsigned long long* __restrict__ init_best, long init_n) {
+  constexpr int MT = mt_rows(C), CP = C + 4;
+  __shared__ __attribute__((aligned(16))) float s_t[MT * CP];
+  __shared__ int s_c[MT];
+  // (the one-to-one table of the assign step that follows this launch starts at "no query": saves a launch per call)
+  if (init_best) {
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (long e = wg * 256 + threadIdx.x; e < init_n; e += (long)gridDim.x * gridDim.y * gridDim.z * 256) init_best[e] = ~0ull;
+  }
   const int b = blockIdx.y;
-  const int n0 = a.n0[b], n1 = a.n1[b];
+  const int n0 = n0p[b], n1 = n1p[b];
   const int q = blockIdx.x * MQ + (threadIdx.x >> 2);
   const int part = threadIdx.x & 3;
   if (blockIdx.x * MQ >= n0) return;     // whole workgroup out of range (uniform)
+  const int nz = gridDim.z, z = blockIdx.z;
+  // this slice's train rows [t_lo, t_hi): whole LDS tiles per slice
+  const int tiles = (n1 + MT - 1) / MT, per = (tiles + nz - 1) / nz;
+  const int t_lo = min(n1, z * per * MT), t_hi = min(n1, (z + 1) * per * MT);
   float qv[C];
-  const float* qp = a.d0 + ((size_t)b * a.max0 + (q < n0 ? q : 0)) * C;
+  const float* qp = d0 + ((size_t)b * max0 + (q < n0 ? q : 0)) * C;
 #pragma unroll
-  for (int c = 0; c < C; ++c) qv[c] = qp[c];
+  for (int c = 0; c < C; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(qp + c);
+    qv[c] = v.x; qv[c + 1] = v.y; qv[c + 2] = v.z; qv[c + 3] = v.w;
+  }
+  const int qc = MASKED ? c0[(size_t)b * max0 + (q < n0 ? q : 0)] : 0;
   float best = INFINITY, second = INFINITY;
   int bi = -1;
-  for (int t0 = 0; t0 < n1; t0 += MT) {
-    const int nt = min(MT, n1 - t0);
+  for (int t0 = t_lo; t0 < t_hi; t0 += MT) {
+    const int nt = min(MT, t_hi - t0);
     __syncthreads();
     for (int e = threadIdx.x; e < MT * C / 4; e += 256) {
-      const int row = e / (C / 4);
+      const int row = e / (C / 4), c4 = e - row * (C / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < nt) v = reinterpret_cast<const float4*>(a.d1 + ((size_t)b * a.max1 + t0) * C)[e];
-      reinterpret_cast<float4*>(s_t)[e] = v;
+      if (row < nt) v = reinterpret_cast<const float4*>(d1 + ((size_t)b * max1 + t0) * C)[e];
+      *reinterpret_cast<float4*>(&s_t[row * CP + 4 * c4]) = v;
     }
+    if (MASKED && threadIdx.x < MT) s_c[threadIdx.x] = threadIdx.x < nt ? c1[(size_t)b * max1 + t0 + threadIdx.x] : -1;
     __syncthreads();
     // this thread scans train rows part, part+4, ... (ascending index inside a thread)
     for (int r = part; r < nt; r += 4) {
-      const float* tp = &s_t[r * C];
+      const float* tp = &s_t[r * CP];
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) { const float d = qv[c] - tp[c]; acc = fmaf(d, d, acc); }
-      const float dist = sqrtf(acc);
+      float dist = sqrtf(acc);
+      if (MASKED && s_c[r] != qc) dist = INFINITY;      // (inf < anything is false: the row is never a neighbour)
       if (dist < best) { second = best; best = dist; bi = t0 + r; }
       else if (dist < second) second = dist;
     }
@@ -61,15 +99,41 @@ __global__ __launch_bounds__(256) void knn2_kernel(const MatchArgs a) {
     best = nb; second = ns;
   }
   if (part == 0 && q < n0) {
-    a.nn_idx[(size_t)b * a.max0 + q] = bi;
-    a.nn_dist[(size_t)b * a.max0 + q] = best;
-    a.nn_dist2[(size_t)b * a.max0 + q] = second;
+    const size_t o = ((size_t)z * gridDim.y + b) * max0 + q;      // z = 0 of a one-slice launch: the outputs themselves
+    nn_idx[o] = bi;
+    nn_dist[o] = best;
+    if (nn_dist2) nn_dist2[o] = second;
   }
 }
 
-__global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* best, long n) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e < n) best[e] = ~0ull;
+// combine the nz partial (best, second, index) triples of every query: slices hold ascending train ranges, so on equal
+// distances the earlier slice (lower index) wins
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ p_idx, const float* __restrict__ p_d,
+                                                         const float* __restrict__ p_d2, int nz, int B, int max0,
+                                                         const int32_t* __restrict__ n0p, int32_t* __restrict__ nn_idx,
+                                                         float* __restrict__ nn_dist, float* __restrict__ nn_dist2,
+                                                         unsigned long long* __restrict__ train_best, int max1, float ratio,
+                                                         int masked) {
+  const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n0p[b]) return;
+  float best = INFINITY, second = INFINITY;
+  int bi = -1;
+  for (int z = 0; z < nz; ++z) {
+    const size_t o = ((size_t)z * B + b) * max0 + q;
+    const float ob = p_d[o], os = p_d2[o];
+    const int oi = p_idx[o];
+    const bool take = ob < best;
+    const float ns = take ? fminf(best, os) : fminf(second, ob);
+    if (take) { best = ob; bi = oi; }
+    second = ns;
+  }
+  const size_t o = (size_t)b * max0 + q;
+  nn_idx[o] = bi;
+  nn_dist[o] = best;
+  if (nn_dist2) nn_dist2[o] = second;
+  // the assign step of the ratio / one-to-one matcher, fused (same rule as match_assign_kernel)
+  if (train_best && bi >= 0 && !(best > ratio * second) && !(masked && !(second < INFINITY)))
+    atomicMin(&train_best[(size_t)b * max1 + bi], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)q);
 }
 
 __global__ __launch_bounds__(256) void match_assign_kernel(const MatchArgs a) {
@@ -80,6 +144,10 @@ __global__ __launch_bounds__(256) void match_assign_kernel(const MatchArgs a) {
   const int t = a.nn_idx[o];
   const float d1 = a.nn_dist[o], d2 = a.nn_dist2[o];
   if (t < 0 || d1 > a.ratio * d2) return;          // feature_matcher.py:190 (needs a second neighbour: d2 = inf passes)
+  // class-masked matching: a class with a single train row has no second neighbour — the reference's per-class
+  // knnMatch(k=2) then yields one-element lists, goodMatchesOneToOne cannot unpack them and match_semantic skips the
+  // whole class (visual_odometry.py:365-376): no match for such a query
+  if (a.cls0 && !(d2 < INFINITY)) return;
   const unsigned long long key = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)q;
   atomicMin(&a.train_best[(size_t)b * a.max1 + t], key);
 }
@@ -95,15 +163,119 @@ __global__ __launch_bounds__(256) void match_emit_kernel(const MatchArgs a) {
   a.match_d[o] = ok ? __uint_as_float((unsigned)(key >> 32)) : 0.f;
 }
 
+// cv2.BFMatcher(crossCheck=True): (q, t) is a match iff t is q's nearest train row and q is t's nearest query
+__global__ __launch_bounds__(256) void match_mutual_kernel(const MatchArgs a) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.max1) return;
+  const size_t o = (size_t)b * a.max1 + t;
+  int q = t < a.n1[b] ? a.rnn_idx[o] : -1;
+  if (q >= 0 && a.nn_idx[(size_t)b * a.max0 + q] != t) q = -1;
+  a.match_q[o] = q;
+  a.match_d[o] = q >= 0 ? a.nn_dist[(size_t)b * a.max0 + q] : 0.f;
+}
+
+// matched rows of every pair, compacted in train order: one workgroup per pair walks the train rows 256 at a time
+__global__ __launch_bounds__(256) void match_pairs_kernel(const PairsArgs a) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < a.max1; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const int q = t < a.max1 ? a.match_q[(size_t)b * a.max1 + t] : -1;
+    const unsigned long long m = __ballot(q >= 0);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (q >= 0) {
+      const size_t o = (size_t)b * a.max1 + off + before;
+      if (a.idx) { a.idx[2 * o] = q; a.idx[2 * o + 1] = t; }
+      if (a.dist) a.dist[o] = a.match_d[(size_t)b * a.max1 + t];
+      if (a.pairs) {
+        const float2 p0 = reinterpret_cast<const float2*>(a.pts0)[(size_t)b * a.max0 + q];
+        const float2 p1 = reinterpret_cast<const float2*>(a.pts1)[(size_t)b * a.max1 + t];
+        reinterpret_cast<float4*>(a.pairs)[o] = make_float4(p0.x, p0.y, p1.x, p1.y);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.count[b] = s_base;
+}
+
+template <int C>
+static void launch_knn2(const float* d0, const float* d1, const int32_t* n0, const int32_t* n1, const int32_t* c0,
+                        const int32_t* c1, int B, int max0, int max1, int nz, int32_t* idx, float* dist, float* dist2,
+                        unsigned long long* init_best, long init_n, hipStream_t s) {
+  dim3 g((max0 + MQ - 1) / MQ, B, nz);
+  if (c0) hipLaunchKernelGGL((knn2_kernel<C, true>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
+  else hipLaunchKernelGGL((knn2_kernel<C, false>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
+}
+
+// one direction of the search; slices of the train range when the grid would leave most of the chip idle.
+// assign: this is the forward search of the ratio / one-to-one matcher — the launch also resets the one-to-one table and,
+// when the search is sliced, the merge launch applies the ratio test and claims train rows (*assigned = true)
+static int knn2(const MatchArgs& a, bool reverse, int32_t* idx, float* dist, float* dist2, bool assign, bool* assigned, hipStream_t s) {
+  const float* d0 = reverse ? a.d1 : a.d0;
+  const float* d1 = reverse ? a.d0 : a.d1;
+  const int32_t* n0 = reverse ? a.n1 : a.n0;
+  const int32_t* n1 = reverse ? a.n0 : a.n1;
+  const int32_t* c0 = reverse ? a.cls1 : a.cls0;
+  const int32_t* c1 = reverse ? a.cls0 : a.cls1;
+  const int max0 = reverse ? a.max1 : a.max0, max1 = reverse ? a.max0 : a.max1;
+  const long wgs = (long)((max0 + MQ - 1) / MQ) * a.B;
+  int nz = 1;
+  if (a.part_idx && wgs < 512) {
+    const int tiles = (max1 + mt_rows(a.C) - 1) / mt_rows(a.C);
+    nz = (int)((1024 + wgs - 1) / wgs);
+    if (nz > tiles) nz = tiles;
+    if (nz > a.part_slices) nz = a.part_slices;
+    if (nz < 1) nz = 1;
+  }
+  int32_t* o_idx = nz > 1 ? a.part_idx : idx;
+  float* o_d = nz > 1 ? a.part_d : dist;
+  float* o_d2 = nz > 1 ? a.part_d2 : dist2;
+  unsigned long long* ib = assign ? a.train_best : nullptr;
+  const long in = (long)a.B * a.max1;
+  switch (a.C) {
+    case 32: launch_knn2<32>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
+    case 64: launch_knn2<64>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
+    case 128: launch_knn2<128>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
+    default: return -1500;
+  }
+  if (assigned) *assigned = false;
+  if (nz > 1) {
+    hipLaunchKernelGGL(knn2_merge_kernel, dim3((max0 + 255) / 256, a.B), dim3(256), 0, s, a.part_idx, a.part_d, a.part_d2, nz,
+                       a.B, max0, n0, idx, dist, dist2, ib, a.max1, a.ratio, a.cls0 ? 1 : 0);
+    if (assigned) *assigned = assign;
+  }
+  return 0;
+}
+
 int launch_match(const MatchArgs& a, hipStream_t s) {
-  if (a.C != 32 && a.C != 64) return -1500;
-  dim3 g0((a.max0 + MQ - 1) / MQ, a.B);
-  if (a.C == 32) hipLaunchKernelGGL(knn2_kernel<32>, g0, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(knn2_kernel<64>, g0, dim3(256), 0, s, a);
-  const long n = (long)a.B * a.max1;
-  hipLaunchKernelGGL(match_init_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, a.train_best, n);
-  hipLaunchKernelGGL(match_assign_kernel, dim3((a.max0 + 255) / 256, a.B), dim3(256), 0, s, a);
+  if (a.C != 32 && a.C != 64 && a.C != 128) return -1500;
+  if ((a.cls0 == nullptr) != (a.cls1 == nullptr)) return -1501;
+  bool assigned = false;
+  if (int e = knn2(a, false, a.nn_idx, a.nn_dist, a.nn_dist2, !a.mutual, &assigned, s)) return e;
+  if (a.mutual) {
+    if (!a.rnn_idx || !a.rnn_dist) return -1502;
+    if (int e = knn2(a, true, a.rnn_idx, a.rnn_dist, nullptr, false, nullptr, s)) return e;
+    hipLaunchKernelGGL(match_mutual_kernel, dim3((a.max1 + 255) / 256, a.B), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+  }
+  // three launches per call: search (+ table reset), [merge +] assign, emit
+  if (!assigned) hipLaunchKernelGGL(match_assign_kernel, dim3((a.max0 + 255) / 256, a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(match_emit_kernel, dim3((a.max1 + 255) / 256, a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_match_pairs(const PairsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(match_pairs_kernel, dim3(a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

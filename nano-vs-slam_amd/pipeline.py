@@ -123,9 +123,20 @@ class FrameStream:
     ``out`` holds the slot's static device tensors: valid until ``slots`` further frames have been submitted (in ``map``:
     until the next iteration).  Work enqueued on the caller's current stream before that submit still sees them intact:
     ``submit`` orders the slot's replay behind the caller's stream.
+
+    ``match=True`` puts the VO loop's matcher on the device too (``VisualOdometry.match``,
+    src/visual_odometry/visual_odometry.py:193-284: ``self.matcher.match(self.prev_descriptors, feat_cur)`` = BF k-NN(2)
+    + ratio test + one-to-one, feature_matcher.py:89-98,179-209; ``semantic=True``: per class, :347-380).  Every slot
+    keeps its frame's selected keypoints and descriptors (and classes) in HBM; a second replayed graph per slot matches
+    the PREVIOUS frame's rows (query) against this frame's (train) — it waits for the previous slot's extraction only,
+    so the frames' extractions still run side by side — and compacts the matched coordinates.  ``result()`` then
+    returns ``(kps0, kps1, dist, out)``: matched keypoints of the previous and of this frame ([m,2] each, the arrays the
+    reference hands to its pose estimation) and the match distances; descriptors never leave the device (8 + 4 bytes
+    per match over PCIe instead of (8 + 4 C) bytes per keypoint).  The first frame has no predecessor: empty arrays.
     """
 
-    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=7):
+    def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=7, match=False,
+                 ratio_test=0.7, semantic=False):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("the frame front-end runs on the HIP device only")
@@ -138,6 +149,14 @@ class FrameStream:
             self.scale = torch.tensor([self.W / float(Ws), self.H / float(Hs)], device=self.dev)
         self.top_k = int(top_k)
         self.slots = int(slots)
+        self.match, self.ratio, self.semantic = bool(match), float(ratio_test), bool(semantic)
+        if self.semantic and not self.match:
+            raise ValueError("semantic=True is a mode of match=True")
+        if self.match and self.slots < 2:
+            raise ValueError("match=True needs at least two slots (the previous frame's rows live in the previous slot)")
+        if self.semantic and not getattr(net, "sample_segmentation", False):
+            raise ValueError("semantic matching needs the class at every cell: set net.sample_segmentation = True "
+                             "(as KP2DtinyFrontend does for its semantic filter)")
         self.copy_stream = torch.cuda.Stream(self.dev)
         # one compute stream per slot (KP2D_FS_SHARED_STREAM=1: the single shared stream of the first version, for A/B)
         shared = os.environ.get("KP2D_FS_SHARED_STREAM", "0") == "1"
@@ -154,6 +173,11 @@ class FrameStream:
                        [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)])
         self.ev_up = [torch.cuda.Event() for _ in range(self.slots)]
         self.ev_done = [torch.cuda.Event() for _ in range(self.slots)]
+        self.ev_extract = [torch.cuda.Event() for _ in range(self.slots)]      # slot's keypoint rows are in HBM
+        self.ev_match = [None] * self.slots                                     # slot's match graph is done (reads the previous slot)
+        self._prev_slot = None        # slot of the frame submitted last (the query side of the next match)
+        self._has_match = {}          # slot -> its frame had a predecessor
+        self.match_graphs, self.rows, self.mhost = [], [], []
         self.graphs, self.outs, self.host = [], [], []
         self._pending = []            # slots in flight, oldest first
         self._next = 0
@@ -188,29 +212,73 @@ class FrameStream:
                                                       self.thr)
         if self.scale is not None:
             pts = pts / self.scale
-        return out, pts, dsel, cnt
+        cls = None
+        if self.semantic:        # class of every selected cell (frontend.py:112-125: seg[mask][top_k])
+            cls = torch.gather(out["seg"].reshape(1, -1), 1, idx.clamp(min=0).long()).to(torch.int32)
+        return out, pts, dsel, cnt, cls
+
+    def _match_step(self, prev, cur, mo, po):
+        """Match slot `prev`'s rows (query) against slot `cur`'s (train) into static buffers: enqueue-only."""
+        from .matching import match_descriptors, match_pairs
+        rp, rc = self.rows[prev], self.rows[cur]
+        mo = match_descriptors(rp["desc"], rp["cnt"], rc["desc"], rc["cnt"], self.ratio, cls0=rp.get("cls"),
+                               cls1=rc.get("cls"), out=mo)
+        po = match_pairs(mo, rp["pts"], rc["pts"], out=po)
+        return mo, po
 
     @torch.no_grad()
     def _capture(self):
         self._precision = self.net.__dict__.get("_precision")
         with torch.cuda.stream(self.compute_stream):
             for _ in range(2):                      # warm-up outside capture: engine handle, workspace, lane objects
-                out, pts, dsel, cnt = self._step(0)
+                out, pts, dsel, cnt, cls = self._step(0)
         self.compute_stream.synchronize()
         self.graphs, self.outs, self.host = [], [], []
+        self.match_graphs, self.rows, self.mhost = [], [], []
         for s in range(self.slots):
             k, cdim = pts.shape[1], dsel.shape[2]
-            host = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, k, 2).pin_memory(),
-                    torch.empty(1, k, cdim).pin_memory())
+            host = None
+            if not self.match:
+                host = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, k, 2).pin_memory(),
+                        torch.empty(1, k, cdim).pin_memory())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.compute_streams[s]):
-                out, pts, dsel, cnt = self._step(s)
-                host[0].copy_(cnt, non_blocking=True)
-                host[1].copy_(pts, non_blocking=True)
-                host[2].copy_(dsel, non_blocking=True)
+                out, pts, dsel, cnt, cls = self._step(s)
+                if host is not None:
+                    host[0].copy_(cnt, non_blocking=True)
+                    host[1].copy_(pts, non_blocking=True)
+                    host[2].copy_(dsel, non_blocking=True)
             self.graphs.append(g)
             self.outs.append(out)
             self.host.append(host)
+            row = {"pts": pts, "desc": dsel, "cnt": cnt}
+            if cls is not None:
+                row["cls"] = cls
+            self.rows.append(row)
+        if self.match:
+            for row in self.rows:         # (captured, never run: the row counts are uninitialised memory until the first replay)
+                row["cnt"].zero_()
+            torch.cuda.synchronize(self.dev)
+            for s in range(self.slots):
+                prev = (s - 1) % self.slots
+                cs = self.compute_streams[s]
+                with torch.cuda.stream(cs):
+                    mo, po = self._match_step(prev, s, None, None)      # allocates the static outputs (outside capture)
+                cs.synchronize()
+                k = self.rows[s]["pts"].shape[1]
+                mh = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, k, 4).pin_memory(),
+                      torch.empty(1, k).pin_memory())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cs):
+                    self._match_step(prev, s, mo, po)
+                    mh[0].copy_(po["count"], non_blocking=True)
+                    mh[1].copy_(po["pairs"], non_blocking=True)
+                    mh[2].copy_(po["dist"], non_blocking=True)
+                self.match_graphs.append(g)
+                self.mhost.append(mh)
+                self.outs[s] = dict(self.outs[s], match=mo, pairs=po, rows=self.rows[s])
+        self._prev_slot = None
+        self.ev_match = [None] * self.slots
         self._sig = self.net._weights_signature()
 
     def submit(self, frame):
@@ -246,16 +314,39 @@ class FrameStream:
         with torch.cuda.stream(cs):
             if not self.zero_copy:
                 cs.wait_event(self.ev_up[s])
+            if self.match:
+                # this slot's rows are the QUERY side of the next slot's match of the previous round: it must be done
+                nxt = (s + 1) % self.slots
+                if self.ev_match[nxt] is not None:
+                    cs.wait_event(self.ev_match[nxt])
             self.graphs[s].replay()
+            if self.match:
+                self.ev_extract[s].record(cs)
+                have_prev = self._prev_slot is not None
+                if have_prev:
+                    cs.wait_event(self.ev_extract[self._prev_slot])      # only the match waits for the previous frame
+                    self.match_graphs[s].replay()
+                    if self.ev_match[s] is None:
+                        self.ev_match[s] = torch.cuda.Event()
+                    self.ev_match[s].record(cs)
+                self._has_match[s] = have_prev
+                self._prev_slot = s
             self.ev_done[s].record(cs)
         self._pending.append(s)
 
     def result(self):
-        """(pts [n,2], feat [n,C], out) of the oldest frame in flight — numpy copies, like ``inference()``."""
+        """(pts [n,2], feat [n,C], out) of the oldest frame in flight — numpy copies, like ``inference()``; with
+        ``match=True``: (kps0 [m,2], kps1 [m,2], dist [m], out) — the matched keypoints of the previous and of this frame."""
         if not self._pending:
             raise RuntimeError("FrameStream: nothing in flight")
         s = self._pending.pop(0)
         self.ev_done[s].synchronize()
+        if self.match:
+            if not self._has_match.get(s, False):
+                return np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros((0,), np.float32), self.outs[s]
+            m = int(self.mhost[s][0][0])
+            pr = self.mhost[s][1][0, :m].numpy()
+            return pr[:, :2].copy(), pr[:, 2:].copy(), self.mhost[s][2][0, :m].numpy().copy(), self.outs[s]
         n = int(self.host[s][0][0])
         return self.host[s][1][0, :n].numpy().copy(), self.host[s][2][0, :n].numpy().copy(), self.outs[s]
 
@@ -263,6 +354,7 @@ class FrameStream:
         for s in self._pending:
             self.ev_done[s].synchronize()
         self._pending = []
+        self._prev_slot = None        # a re-capture or weight upload breaks the chain: the next frame has no predecessor
 
     def map(self, frames):
         """Run an iterable of frames through the stream, one frame of look-ahead; yields in order."""

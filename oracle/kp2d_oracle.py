@@ -755,5 +755,41 @@ def bf_match_one_to_one(des1, des2, ratio=0.7):
     return best, nn, d1, d2
 
 
+def bf_match_semantic(des1, cls1, des2, cls2, ratio=0.7, n_classes=28):
+    """VisualOdometry.match_semantic as written — src/visual_odometry/visual_odometry.py:347-380: for every class id the
+    BF one-to-one match between the previous frame's keypoints of that class (query) and the current frame's (train),
+    index lists concatenated.  A class with fewer than two train rows has no second neighbour: the reference's
+    knnMatch(k=2) returns one-element lists, goodMatchesOneToOne raises on `for m, n in matches` and the bare except skips
+    the class; an empty side skips it too.  (As shipped the loop unpacks two values from a three-value return, so its
+    except fires for EVERY class: this restates what the loop is written to compute.)  Returns {trainIdx: (queryIdx, d)}
+    over the full arrays."""
+    des1 = np.asarray(des1, np.float32)
+    des2 = np.asarray(des2, np.float32)
+    cls1 = np.asarray(cls1).reshape(-1)
+    cls2 = np.asarray(cls2).reshape(-1)
+    out = {}
+    for c in range(n_classes):
+        i1 = np.where(cls1 == c)[0]
+        i2 = np.where(cls2 == c)[0]
+        if len(i1) == 0 or len(i2) < 2:
+            continue
+        best, *_ = bf_match_one_to_one(des1[i1], des2[i2], ratio)
+        for t, (q, d) in best.items():
+            out[int(i2[t])] = (int(i1[q]), d)
+    return out
+
+
+def bf_match_crosscheck(des1, des2):
+    """cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match — src/evaluation/descriptor.py:221-222, restated: (q, t) is
+    kept iff t is the nearest train row of q and q the nearest query of t (L2, lowest index on ties).
+    Returns {trainIdx: (queryIdx, distance)}."""
+    des1 = np.asarray(des1, np.float32)
+    des2 = np.asarray(des2, np.float32)
+    d = np.sqrt(((des1[:, None, :] - des2[None, :, :]) ** 2).sum(-1, dtype=np.float32))
+    nn = np.argmin(d, axis=1)
+    rnn = np.argmin(d, axis=0)
+    return {int(t): (int(q), float(d[q, t])) for t, q in enumerate(rnn) if nn[q] == t}
+
+
 def cast_params(p, dtype):
     return {k: (v.astype(dtype) if v.dtype.kind == "f" else v) for k, v in p.items()}

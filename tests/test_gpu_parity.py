@@ -1125,3 +1125,194 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
             kth = ref_scores[r][ref].min() if len(ref) else 0.7
             bound = 0.7 if len(z[f"keep_idx_{r}"]) <= k else kth
             _same_set(got, ref, ref_scores[r], bound, label=f"headline-batch[{precision}] K1 top-{k} frame {b}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: matcher variants (class-masked, mutual nearest neighbours, 128-d descriptors, sliced search, compaction)
+# ---------------------------------------------------------------------------------------------------------------------
+def _match_problem(rng, B, k0, k1, C, n_true):
+    d0 = rng.standard_normal((B, k0, C)).astype(np.float32)
+    d1 = rng.standard_normal((B, k1, C)).astype(np.float32)
+    for b in range(B):
+        src = rng.permutation(k1)[:n_true]
+        d0[b, :n_true] = d1[b, src] + 0.05 * rng.standard_normal((n_true, C)).astype(np.float32)
+        d0[b, n_true:n_true + 10] = d0[b, :10]          # exact duplicates: the one-to-one rule and distance ties
+    d0 /= np.linalg.norm(d0, axis=-1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
+    return d0, d1
+
+
+def _pairs_equal(got_q, ref, dd1=None, dd2=None, ratio=None):
+    got = {int(t): int(q) for t, q in enumerate(got_q) if q >= 0}
+    want = {t: q for t, (q, _) in ref.items()}
+    for t in set(got) ^ set(want):                      # only where the ratio test sits on its fp32 boundary
+        assert dd1 is not None, (t, got.get(t), want.get(t))
+        q = got.get(t, want.get(t))
+        assert abs(dd1[q] - ratio * dd2[q]) < 1e-5, (t, q)
+    assert all(got[t] == want[t] for t in set(got) & set(want))
+    return len(got)
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_descriptor_matching_widths_and_sliced_search(C):
+    """C = 128 (LARGE_D descriptors, kp2dtiny.py:169-188) and the sliced search: with few pairs one query's train rows
+    are spread over several workgroups and merged — the result must be the one-slice result, bit for bit, and the oracle's."""
+    from nano_vs_slam_amd.matching import match_descriptors
+    rng = np.random.default_rng(40 + C)
+    B, k0, k1 = 2, 900, 1100
+    d0, d1 = _match_problem(rng, B, k0, k1, C, 300)
+    n0 = np.array([900, 517], np.int32)
+    n1 = np.array([1100, 3], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    r = match_descriptors(t(d0), t(n0), t(d1), t(n1), 0.7)                      # sliced (2 pairs x 15 workgroups < 512)
+    big = 40                                                                      # 40 copies: 600 workgroups, one slice
+    rb = match_descriptors(t(np.tile(d0, (big, 1, 1))), t(np.tile(n0, big)), t(np.tile(d1, (big, 1, 1))), t(np.tile(n1, big)), 0.7)
+    for k in ("nn_idx", "nn_dist", "nn_dist2", "match_q", "match_d"):
+        for b in range(B):
+            nq = n0[b] if k.startswith("nn") else k1
+            assert torch.equal(r[k][b, :nq], rb[k][b, :nq]), (k, b)
+            assert torch.equal(r[k][b, :nq], rb[k][2 * (big - 1) + b, :nq]), (k, b)
+    for b in range(B):
+        best, nn, dd1, dd2 = orc.bf_match_one_to_one(d0[b, :n0[b]], d1[b, :n1[b]], 0.7)
+        assert np.array_equal(r["nn_idx"][b, :n0[b]].cpu().numpy(), nn)
+        assert np.max(np.abs(r["nn_dist"][b, :n0[b]].cpu().numpy() - dd1)) < 2e-5
+        n = _pairs_equal(r["match_q"][b].cpu().numpy(), best, dd1, dd2, 0.7)
+        assert n > 100 or b > 0
+
+
+def test_descriptor_matching_per_class():
+    """match_semantic (visual_odometry.py:347-380) as one class-masked launch vs the per-class loop of the oracle: classes
+    that are empty on one side, a class with ONE train row (no second neighbour: skipped, as the reference's knnMatch(k=2)
+    path does), exact duplicate descriptors inside a class."""
+    from nano_vs_slam_amd.matching import bf_match_semantic, match_descriptors
+    rng = np.random.default_rng(77)
+    B, k0, k1, C = 2, 600, 640, 32
+    d0, d1 = _match_problem(rng, B, k0, k1, C, 250)
+    c0 = rng.integers(0, 28, (B, k0)).astype(np.int32)
+    c1 = rng.integers(0, 28, (B, k1)).astype(np.int32)
+    for b in range(B):
+        # true correspondences mostly share their class; class 5 absent from the train side, 6 from the query side,
+        # class 7 has a single train row, class 27 (the last id) is populated
+        nn_true = np.argmin(((d0[b, :250, None, :] - d1[b, None, :, :]) ** 2).sum(-1), axis=1)
+        c0[b, :250] = c1[b, nn_true]
+        c1[b][c1[b] == 5] = 4
+        c0[b][c0[b] == 6] = 4
+        c1[b][c1[b] == 7] = 8
+        c1[b, 17] = 7
+        c0[b, 300:310] = 7
+    n0 = np.array([600, 333], np.int32)
+    n1 = np.array([640, 640], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    r = match_descriptors(t(d0), t(n0), t(d1), t(n1), 0.7, cls0=t(c0), cls1=t(c1))
+    for b in range(B):
+        ref = orc.bf_match_semantic(d0[b, :n0[b]], c0[b, :n0[b]], d1[b, :n1[b]], c1[b, :n1[b]], 0.7)
+        got_q = r["match_q"][b].cpu().numpy()
+        # ratio-boundary tolerance needs the class-restricted distances: recompute them per query from the oracle side
+        dd1 = np.full(n0[b], np.inf, np.float32)
+        dd2 = np.full(n0[b], np.inf, np.float32)
+        for q in range(n0[b]):
+            same = np.where(c1[b, :n1[b]] == c0[b, q])[0]
+            if len(same):
+                d = np.sort(np.sqrt(((d0[b, q] - d1[b, same]) ** 2).sum(-1, dtype=np.float32)))
+                dd1[q] = d[0]
+                dd2[q] = d[1] if len(d) > 1 else np.inf
+        n = _pairs_equal(got_q, ref, dd1, dd2, 0.7)
+        assert n > 60, n
+        matched_t = np.where(got_q >= 0)[0]
+        assert np.all(c1[b, matched_t] == c0[b, got_q[matched_t]])            # never across classes
+        assert not np.any(c1[b, matched_t] == 7)                               # the single-train-row class is skipped
+        nn = r["nn_idx"][b, :n0[b]].cpu().numpy()
+        assert np.all(nn[c0[b, :n0[b]] == 5] == -1)                            # no train row of that class at all
+    i1, i2, sc = bf_match_semantic(d0[0], c0[0], d1[0], c1[0], 0.7)
+    ref = orc.bf_match_semantic(d0[0], c0[0], d1[0], c1[0], 0.7)
+    assert {t_: q for q, t_ in zip(i1, i2)} == {t_: q for t_, (q, _) in ref.items()}
+
+
+def test_descriptor_matching_mutual_and_compaction():
+    """crossCheck=True (descriptor.py:221-222): mutual nearest neighbours; crossCheck=False: nn_idx; and the compact
+    (x0, y0, x1, y1) lists the VO loop takes to the host."""
+    from nano_vs_slam_amd.matching import bf_match_crosscheck, bf_match_nn, match_descriptors, match_pairs
+    rng = np.random.default_rng(5)
+    B, k0, k1, C = 3, 500, 450, 32
+    d0, d1 = _match_problem(rng, B, k0, k1, C, 200)
+    n0 = np.array([500, 1, 77], np.int32)
+    n1 = np.array([450, 450, 1], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    r = match_descriptors(t(d0), t(n0), t(d1), t(n1), mutual=True)
+    p0 = rng.uniform(0, 320, (B, k0, 2)).astype(np.float32)
+    p1 = rng.uniform(0, 320, (B, k1, 2)).astype(np.float32)
+    pr = match_pairs(r, t(p0), t(p1))
+    for b in range(B):
+        ref = orc.bf_match_crosscheck(d0[b, :n0[b]], d1[b, :n1[b]])
+        got_q = r["match_q"][b].cpu().numpy()
+        _pairs_equal(got_q, ref)
+        assert np.all(got_q[n1[b]:] == -1)
+        cnt = int(pr["count"][b])
+        assert cnt == len(ref)
+        ts = np.where(got_q >= 0)[0]
+        assert np.array_equal(pr["idx"][b, :cnt].cpu().numpy(), np.stack([got_q[ts], ts], 1))
+        want = np.concatenate([p0[b][got_q[ts]], p1[b][ts]], 1)
+        assert np.array_equal(pr["pairs"][b, :cnt].cpu().numpy(), want)
+        assert np.allclose(pr["dist"][b, :cnt].cpu().numpy(), [ref[int(t_)][1] for t_ in ts], atol=2e-5)
+    i1, i2, sc = bf_match_crosscheck(d0[0], d1[0])
+    assert {t_: q for q, t_ in zip(i1, i2)} == {t_: q for t_, (q, _) in orc.bf_match_crosscheck(d0[0], d1[0]).items()}
+    q, tr, ds = bf_match_nn(d0[0], d1[0])
+    dmat = np.sqrt(((d0[0][:, None] - d1[0][None]) ** 2).sum(-1, dtype=np.float32))
+    assert q == list(range(k0)) and np.array_equal(tr, np.argmin(dmat, 1))
+    assert bf_match_nn(d0[0][:0], d1[0]) == ([], [], [])
+
+
+@pytest.mark.parametrize("semantic", [False, True])
+def test_frame_stream_matches_consecutive_frames_on_the_device(semantic):
+    """FrameStream(match=True): the VO loop's matcher inside the replayed graphs (visual_odometry.py:193-284 / :347-380).
+    For every frame after the first, the (kps0, kps1) pairs it returns are the reference-side result: inference() per
+    frame, then the oracle's BF k-NN(2) + ratio + one-to-one (per class: match_semantic) between the previous frame's
+    rows and this frame's.  More frames than slots, so slots are reused while matches of the previous round complete."""
+    from nano_vs_slam_amd.pipeline import FrameStream, inference
+    from nano_vs_slam_amd.selectors import select_and_gather
+    model, sd = product_model("S", False, 28)
+    model.sample_segmentation = semantic
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    # consecutive frames = the same scene shifted by a few pixels plus noise: real correspondences
+    frames = []
+    for i in range(10):
+        f = np.roll(base, (i // 2, i), axis=(0, 1)).astype(np.int16) + rng.integers(-6, 7, base.shape)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    rows = []
+    for f in frames:
+        pts, feat, out = inference(model, f, None, nn_thresh=0.5, top_k=300)
+        cls = None
+        if semantic:
+            idx, _v, cnt, _p, _d = select_and_gather(out["score"], out["coord"], out["feat"], 300, 0.5)
+            cls = out["seg"].reshape(-1)[idx[0, :int(cnt[0])].long()].cpu().numpy()
+        rows.append((pts, feat, cls))
+    fs = FrameStream(model, (96, 128), None, nn_thresh=0.5, top_k=300, device=DEV, slots=4, match=True, semantic=semantic)
+    got = list(fs.map(frames))
+    assert len(got) == len(frames)
+    k0, k1, dist, out = got[0]
+    assert k0.shape == (0, 2) and k1.shape == (0, 2) and dist.shape == (0,)
+    total = 0
+    for i in range(1, len(frames)):
+        (p_prev, f_prev, c_prev), (p_cur, f_cur, c_cur) = rows[i - 1], rows[i]
+        if semantic:
+            ref = orc.bf_match_semantic(f_prev, c_prev, f_cur, c_cur, 0.7)
+        else:
+            ref, *_ = orc.bf_match_one_to_one(f_prev, f_cur, 0.7)
+        k0, k1, dist, out = got[i]
+        want = {t: q for t, (q, _) in ref.items()}
+        # the stream returns coordinates: map them back to rows (keypoints of a frame are distinct cells)
+        pos_prev = {tuple(p): j for j, p in enumerate(p_prev)}
+        pos_cur = {tuple(p): j for j, p in enumerate(p_cur)}
+        gotd = {pos_cur[tuple(b)]: pos_prev[tuple(a)] for a, b in zip(k0, k1)}
+        diff = set(gotd) ^ set(want)
+        assert len(diff) <= 1 and all(gotd[t] == want[t] for t in set(gotd) & set(want)), (i, len(gotd), len(want), diff)
+        assert np.all(np.diff([pos_cur[tuple(b)] for b in k1]) > 0)            # train order
+        for a, b, d in zip(k0, k1, dist):
+            dd = np.sqrt(((f_prev[pos_prev[tuple(a)]] - f_cur[pos_cur[tuple(b)]]) ** 2).sum(dtype=np.float32))
+            assert abs(dd - d) < 2e-5
+        total += len(gotd)
+        assert out["rows"]["cnt"].shape == (1,) and "match" in out
+    assert total > 5, total        # (random-weight descriptors: few survive the ratio test)
+    with pytest.raises(ValueError):
+        FrameStream(model, (96, 128), None, slots=1, match=True)

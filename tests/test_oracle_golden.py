@@ -101,3 +101,24 @@ def test_only_encoder_and_netvlad_init_match_reference(name):
     alpha, cent, w = orc.netvlad_init_params(z["init_clsts"].copy(), z["init_descs"].copy())
     assert abs(alpha - float(z["init_alpha"])) < 1e-9 * abs(alpha)
     assert np.array_equal(w, z["init_conv_weight"]) and np.array_equal(cent, z["init_centroids"])
+
+
+def test_matcher_variants_on_hand_made_cases():
+    """Known answers for the matcher restatements of the oracle (parity unpinned otherwise: cv2 is not installed here and
+    the reference holds no match vectors — the restatements follow feature_matcher.py:179-209, visual_odometry.py:347-380
+    and OpenCV's documented BFMatcher semantics)."""
+    from oracle import kp2d_oracle as orc
+    e = np.eye(4, dtype=np.float32)
+    q = np.stack([e[0], e[1], e[0] * 0.9 + e[1] * 0.1, e[3]])
+    t = np.stack([e[0], e[1], e[2]])
+    # one-to-one: queries 0 and 2 both point at train 0; query 0 (distance 0) keeps it.  Query 3 is equidistant from all
+    # three train rows: ratio test 1.0 <= 0.7 fails
+    best, nn, d1, d2 = orc.bf_match_one_to_one(q, t, 0.7)
+    assert best == {0: (0, 0.0), 1: (1, 0.0)} and list(nn) == [0, 1, 0, 0]
+    # mutual nearest neighbours: train 2's nearest query is query 0 (lowest index among ties), whose nearest train is 0
+    assert orc.bf_match_crosscheck(q, t) == {0: (0, 0.0), 1: (1, 0.0)}
+    # per class: class 0 = {q0, q2} x {t0, t2}, class 1 = {q1, q3} x {t1} -> a single train row, skipped as a whole
+    sem = orc.bf_match_semantic(q, [0, 1, 0, 1], t, [0, 1, 0], 0.7)
+    assert sem == {0: (0, 0.0)}
+    # a class without queries or without train rows contributes nothing
+    assert orc.bf_match_semantic(q, [2, 2, 2, 2], t, [0, 0, 0], 0.7) == {}

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--pinned", action="store_true")
     ap.add_argument("--eager", action="store_true", help="batch 1 only: call inference() per frame instead of FrameStream")
     ap.add_argument("--slots", type=int, default=7, help="batch 1 only: FrameStream slots (frames in flight)")
+    ap.add_argument("--match", action="store_true", help="batch 1 only: match every frame against its predecessor on the device")
+    ap.add_argument("--semantic", action="store_true", help="with --match: per-class matching (match_semantic)")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import FrameStream, inference
@@ -34,17 +36,26 @@ def main():
     src = torch.from_numpy(frames).pin_memory() if a.pinned else frames
     if a.batch == 1 and not a.eager:
         # the VO loop: one frame per call, replayed HIP graph + overlapped upload (pipeline.FrameStream)
-        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0", slots=a.slots)
-        seq = [frames[0]] * a.steps
+        if a.semantic:
+            net.sample_segmentation = True
+        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0", slots=a.slots, match=a.match, semantic=a.semantic)
+        rng = np.random.default_rng(1)
+        seq = [np.roll(frames[0], (i % 5, i % 7), axis=(0, 1)) for i in range(a.steps)] if a.match else [frames[0]] * a.steps
         for _ in fs.map(seq[:5]):
             pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = sum(1 for _ in fs.map(seq))
+        n, nm = 0, 0
+        for r in fs.map(seq):
+            n += 1
+            nm += len(r[0])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. H2D of uint8 frames and D2H of keypoints",
+        what = ("extract + select + match against the previous frame (" + ("per class, " if a.semantic else "") + "BF k-NN(2) + ratio + "
+                "one-to-one) on the device, D2H of the matched coordinate pairs only") if a.match else "H2D of uint8 frames and D2H of keypoints"
+        print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. " + what,
                           "value": round(1e3 / ms, 1), "ms_per_step": round(ms, 3), "batch": 1,
+                          "rows_per_frame": round(nm / n, 1),
                           "mode": f"FrameStream (HIP graph replay, {a.slots} pinned slots, "
                                   + ("ONE shared compute stream" if os.environ.get("KP2D_FS_SHARED_STREAM") == "1"
                                      else "a compute stream and workspace per slot") + ")"}))
