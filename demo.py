@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--weights", default="./demo_data/V3_S_A_p_best.ckpt")
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
+    ap.add_argument("--no-match", action="store_true", help="extract only (keypoints and descriptors to the host), as in round 3")
     a = ap.parse_args()
     model = tiny_factory("S_A", 28, v3=True).cpu()
     if os.path.exists(a.weights):
@@ -47,14 +48,32 @@ def main():
         for _ in range(n):
             f = np.roll(f, 3, axis=1)                                         # a panning "video"
             yield f
-    fs = FrameStream(model, frame.shape[:2], new_size, device=a.device)
+    if a.no_match:
+        fs = FrameStream(model, frame.shape[:2], new_size, device=a.device)
+        t0 = time.perf_counter()
+        for pts, feat, out in fs.map(video(a.frames, frame)):
+            n_kp.append(len(pts))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{a.frames} frames, {a.frames / dt:.1f} frames/s (single-frame latency path), "
+              f"{np.mean(n_kp):.0f} keypoints/frame, descriptor dim {feat.shape[1] if len(feat) else 0}, "
+              f"seg classes seen {int(out['seg'].unique().numel())}")
+        return
+    # the VO loop's next step on the device too (visual_odometry.py:193-284: matcher.match(prev_descriptors, feat_cur)):
+    # every frame is matched against its predecessor inside the replayed graphs; the host receives the matched coordinate
+    # pairs (what estimatePose takes), never the descriptors
+    fs = FrameStream(model, frame.shape[:2], new_size, device=a.device, match=True)
+    n_m = []
     t0 = time.perf_counter()
-    for pts, feat, out in fs.map(video(a.frames, frame)):
-        n_kp.append(len(pts))
+    for kps0, kps1, dist, out in fs.map(video(a.frames, frame)):
+        n_m.append(len(kps0))
+        n_kp.append(int(out["rows"]["cnt"][0]))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{a.frames} frames, {a.frames / dt:.1f} frames/s (single-frame latency path), "
-          f"{np.mean(n_kp):.0f} keypoints/frame, descriptor dim {feat.shape[1] if len(feat) else 0}, "
+    shift = np.median(kps1[:, 0] - kps0[:, 0]) if len(kps0) else float("nan")
+    print(f"{a.frames} frames, {a.frames / dt:.1f} frames/s (extract + select + match, single-frame latency path), "
+          f"{np.mean(n_kp):.0f} keypoints/frame, {np.mean(n_m[1:]) if len(n_m) > 1 else 0:.0f} matches/frame, "
+          f"median x displacement of the last frame's matches {shift:.2f} px (the synthetic video pans by 3), "
           f"seg classes seen {int(out['seg'].unique().numel())}")
 
 

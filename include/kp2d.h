@@ -218,6 +218,8 @@ int kp2d_set_chunk_frames(kp2d_model* m, int frames);
  *   "wsm_min_items"  least number of (16 x 32 pixel tile, 64-channel group) work items of a launch for the
  *                    warp-specialised persistent form of the multi-chunk 3x3 layers (conv3x3_wsm.hip);
  *                    0 = automatic (KP2D_WSM if set, else one item per workgroup of the launch), -1 = never.
+ *   "ws_min_tiles"   least 16 x 32 pixel tiles of a launch for the warp-specialised form of backbone.conv1b
+ *                    (conv3x3_f16x3_ws_kernel); 0 = default (1024).
  *   "wsm_grid"       most workgroups of that form per launch (0 = KP2D_WSM_GRID if set, else CUs / stream lanes).
  * Unknown keys return KP2D_ERR_ARG.  kp2d_profile_get reports the tile form each conv launch took behind its kernel
  * family ("conv3x3_f16x3<wsm>", "conv3x3_f16x3<2,1,16>", ...). */

@@ -363,6 +363,9 @@ constexpr int WS_W = 2 * WS_IMG;                       // weight planes behind t
 constexpr int WS_LDS = WS_W + 2 * WS_WL;               // 101,376 B
 constexpr int WS_G = WS_ROWS * WS_COLS * 4;            // 16-byte granules of a halo tile (2448)
 constexpr int WS_IT = (WS_G + 255) / 256;              // per staging thread (10)
+// trips of BOTH role loops of a workgroup that walks tiles t0, t0 + G, ... two per trip (the barrier contract below)
+constexpr int WS_BARRIERS_PER_TRIP = 2;
+__host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (ntiles - t0 + 2 * G - 1) / (2 * G); }
 }  // namespace
 
 __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const int ntiles) {
@@ -512,18 +515,31 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   // in iteration i they commit tile i + 1 into image (i + 1) & 1 and request tile i + 3 into the set just freed.  Every
   // request / commit runs unconditionally (tiles past the end load and commit zeros nobody reads), so that each path has
   // the same number of loads in flight and the waits in front of a commit stay partial.
-  // The two jobs are two separate loops with the same barrier count (one before, two per trip): in a shared loop the
-  // staging registers would be live through the multiply code as far as the compiler can tell (57 spilled registers).
+  // The two jobs are two separate loops: in a shared loop the staging registers would be live through the multiply code
+  // as far as the compiler can tell (57 spilled registers).
+  //
+  // BARRIER CONTRACT.  s_barrier counts waves, not source lines: every wave of the workgroup must execute the same NUMBER
+  // of barriers, from whichever loop.  That holds because
+  //   (1) the role branch is wave-uniform — `consumer` comes from readfirstlane(tid >> 6), all 64 lanes of a wave agree —
+  //       so no barrier is ever reached by part of a wave;
+  //   (2) both loops run ws_trips(...) trips — ONE expression, evaluated once, before the branch — and each trip executes
+  //       exactly WS_BARRIERS_PER_TRIP barriers, after the one barrier in front of the loops (1 + 2 trips in all);
+  //   (3) no barrier sits under any other condition (the second multiply of a trip is conditional, its barrier is not).
+  // tests/test_gpu_parity.py::test_warp_specialised_conv1b_trip_count_edges runs odd tile counts, fewer tiles than
+  // workgroups and 2 G + 1 tiles against the general kernel.
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   const int G = gridDim.x, t0 = blockIdx.x;
+  const int trips = ws_trips(ntiles, t0, G);         // the launcher keeps G <= ntiles, so t0 < ntiles and trips >= 1
   if (consumer) {
     __syncthreads();
-    for (int t = t0; t < ntiles; t += 2 * G) {
+    for (int k = 0; k < trips; ++k) {
+      const int t = t0 + 2 * k * G;
       multiply(t, 0);
       __syncthreads();
       if (t + G < ntiles) multiply(t + G, 1);
       __syncthreads();
+      static_assert(WS_BARRIERS_PER_TRIP == 2, "multiplying loop: two barriers per trip");
     }
   } else {
     request(t0, S0{});
@@ -531,13 +547,15 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
     request(t0 + G, S0{});
     request(t0 + 2 * G, S1{});
     __syncthreads();
-    for (int t = t0; t < ntiles; t += 2 * G) {
+    for (int k = 0; k < trips; ++k) {
+      const int t = t0 + 2 * k * G;
       commit(1, S0{});
       request(t + 3 * G, S0{});
       __syncthreads();
       commit(0, S1{});
       request(t + 4 * G, S1{});
       __syncthreads();
+      static_assert(WS_BARRIERS_PER_TRIP == 2, "staging loop: two barriers per trip");
     }
   }
 }
@@ -610,7 +628,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   // single-chunk, max-pooled, 32 channels (conv1b) on grids that fill the chip several times: warp-specialised persistent form
   static const bool ws_on = !(getenv("KP2D_WS") && getenv("KP2D_WS")[0] == '0');
   if (ws_on && a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.store == ST_NHWC_POOL && a.act <= ACT_RELU &&
-      !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= 1024 &&
+      !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= (a.ws_min > 0 ? a.ws_min : 1024) &&
       (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
   { g_variant = "<ws>"; return launch_ws(a, s); }
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');

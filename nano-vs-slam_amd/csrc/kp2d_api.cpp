@@ -142,6 +142,7 @@ struct kp2d_model {
   float* blob = nullptr;
   bool finalized = false;
   int chunk_frames = 0;
+  int ws_min = 0;         // kp2d_set_option("ws_min_tiles"): least tiles of a launch for the warp-specialised conv1b form (0 = 1024)
   int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
   int precision = KP2D_PREC_F16X3;
@@ -642,6 +643,7 @@ struct Plan {
     a.prec = split ? 1 : 0;
     a.wsm_min = m->wsm_min;
     a.wsm_grid = m->wsm_grid;
+    a.ws_min = m->ws_min;
     a.wsm_lanes = nlanes;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
@@ -1535,6 +1537,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "wsm_min_items") {
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "wsm_min_items out of range");
     m->wsm_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "ws_min_tiles") {
+    if (value < 0 || value > 0x7fffffffL) return fail(KP2D_ERR_ARG, "ws_min_tiles out of range");
+    m->ws_min = (int)value;
     return KP2D_OK;
   }
   if (k == "wsm_grid") {

@@ -1316,3 +1316,28 @@ def test_frame_stream_matches_consecutive_frames_on_the_device(semantic):
     assert total > 5, total        # (random-weight descriptors: few survive the ratio test)
     with pytest.raises(ValueError):
         FrameStream(model, (96, 128), None, slots=1, match=True)
+
+
+@pytest.mark.parametrize("B,H,W,tiles", [(1, 304, 864, 513), (1, 80, 96, 15), (1, 112, 1184, 259), (2, 48, 160, 15)])
+def test_warp_specialised_conv1b_trip_count_edges(B, H, W, tiles):
+    """conv3x3_f16x3_ws_kernel's two role loops must run the same number of barriers whatever the tile count: 2 G + 1 tiles
+    (513 on 256 workgroups: one workgroup walks three tiles, its second trip has only a first half), an odd count below
+    the number of CUs (15: one tile per workgroup, G = ntiles), G + 3 tiles (259), and a two-frame batch that the two stream
+    lanes split into one frame each.  Forced with ws_min_tiles = 1, against the general kernel (ws_min_tiles = huge)."""
+    model, _ = product_model("S", False, 28)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=9)).to(DEV)
+    assert (W // 32) * ((H + 15) // 16) * B == tiles or B == 2
+    with torch.no_grad():
+        model(x[:1])
+        eng = model._engine
+        assert eng.lib.kp2d_set_option(eng.handle, b"ws_min_tiles", 1 << 30) == 0
+        ran = _kernels_that_ran(model, x)
+        assert not any("<ws>" in k for k in ran["backbone.conv1b"])
+        ref = {k: v.clone() for k, v in model(x).items()}
+        assert eng.lib.kp2d_set_option(eng.handle, b"ws_min_tiles", 1) == 0
+        ran = _kernels_that_ran(model, x)
+        assert all("<ws>" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
+        got = {k: v.clone() for k, v in model(x).items()}
+        assert eng.lib.kp2d_set_option(eng.handle, b"ws_min_tiles", 0) == 0
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k

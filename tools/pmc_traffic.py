@@ -18,7 +18,10 @@ def family(name):
         return ("conv3x3" if taps == "9" else "conv1x1") + ("_f16x3" if prec == "1" else "_f32")
     if n.startswith("head3x3_kernel"):
         return "conv3x3_head"
-    if n.startswith("conv3x3_f16x3_kernel"):      # conv3x3_f16.hip (16x16x32 MFMA), both tile widths
+    # conv3x3_f16.hip / conv3x3_wsm.hip: every tile form of the split-fp16 3x3 convolution is ONE family, the one bench.py's
+    # roofline object and its algorithmic_bytes_per_launch cover (round 3 kept the warp-specialised conv1b kernel under its
+    # own key, so `traffic` covered 24 of the 25 launches)
+    if n.startswith("conv3x3_f16x3"):
         return "conv3x3_f16x3"
     return n.split("<")[0].replace("_kernel", "")
 
