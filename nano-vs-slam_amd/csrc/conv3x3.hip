@@ -425,8 +425,12 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
       const float t = fmaf(acc[c], a.scale[c], a.shift[c]);     // uniform index: scalar loads
       acc[c] = fmaxf(t, t * slope);
     }
+    // a thread's four float4 go to slots j ^ ((tid >> 1) & 3) of its 64-byte row: straight slots put lanes t, t + 2, t + 4,
+    // t + 6 of every 8-lane store group on the same banks (64-byte lane stride = 16 of the 32 store banks): 4-way
+    // conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.667 (profiles/r3_pmc_summary.txt)
 #pragma unroll
-      for (int c = 0; c < CO; c += 4) s_o[threadIdx.x * 4 + c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+      for (int c = 0; c < CO; c += 4)
+        s_o[threadIdx.x * 4 + ((c / 4) ^ ((threadIdx.x >> 1) & 3))] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
   }
   // The 256 pixels of this workgroup are one contiguous 16 KiB run of the NHWC output: go through LDS so every
   // store instruction of a wave writes 1 KiB of consecutive bytes (per-thread 64-byte rows cost 1.6x the write
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const Conv1aArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = j * 256 + threadIdx.x;          // float4 index inside the block's run
-    if (base + (e >> 2) < npix) dst[e] = s_o[e];
+    if (base + (e >> 2) < npix) dst[e] = s_o[(e & ~3) | ((e & 3) ^ ((e >> 3) & 3))];      // (undo the slot swizzle of pixel e >> 2)
   }
 }
 

@@ -29,7 +29,15 @@ __device__ __forceinline__ void head3x3_body(const ConvArgs& a, float* const s_i
   float* const s_part = s_in + HD_HY * HD_ROW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile order (as the conv kernels): workgroups are dealt round-robin over the 8 XCDs, each with its own L2;
+  // in launch order the tiles that share halo rows sat on eight different L2s and every one of them fetched the halo from
+  // HBM — PMC read 127 MB per launch against 78.6 MB algorithmic = the 6 x 18 / 4 x 16 halo ratio (profiles/r3_traffic.json).
+  // Every XCD now owns a contiguous run of tiles, so a tile's neighbours hit in its L2.
   int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
