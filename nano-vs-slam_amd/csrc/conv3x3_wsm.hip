@@ -103,6 +103,11 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     return r;
   };
 
+#ifdef KP2D_ABLATE
+  // (experiment: start the workgroups out of step — every CU otherwise reaches its items' store bursts together)
+  if (KP2D_DBG_ON(1024)) for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(33);
+  if (KP2D_DBG_ON(2048)) for (int i = 0; i < (int)(blockIdx.x & 3); ++i) __builtin_amdgcn_s_sleep(100);
+#endif
   // per-channel scale | shift of the whole layer -> LDS (the multiplying waves read 4 channels per ds_read_b128)
   for (int c = tid; c < a.npad; c += M_THREADS) {
     smem[M_SS / 4 + c] = a.scale[c];
@@ -357,8 +362,13 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
           const float t = fmaf(acc[m][n][r], sc[r], sh[r]);
           v[r] = fmaxf(t, t * slope);
         }
-        if (full)
+        if (full) {
+#ifdef KP2D_ABLATE
+          if (KP2D_DBG_ON(4096)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, (vo[m] + s0) | cinv, 0, 2);      // (experiment: nt)
+          else
+#endif
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, KP2D_DBG_ON(64) ? OOB : ((vo[m] + s0) | cinv), 0, 0);
+        }
         if (pooled) {
           // the 2 x 2 pixel block of a pooled pixel = lanes 4 q .. 4 q + 3: maximum over the quad in two DPP steps per
           // value.  v_max_f32_dpp by hand (the builtin form costs a v_mov_dpp + two v_max per step); the s_nop covers
