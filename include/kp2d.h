@@ -211,6 +211,13 @@ int kp2d_get_precision(const kp2d_model* m);
  * the tests compare the kernels with the reference's recorded intermediates (tests/golden *_taps fixtures) layer by
  * layer.  layer = NULL or dst = NULL switches it off. */
 int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_floats);
+/* The next kp2d_forward / kp2d_forward_frames calls (not ONLY_ENCODER) also write the dense class map — the argmax over
+ * the class planes of `seg`, what post_processing computes first (kp2dtiny.py:609 / :975) — to ids [B,1,H2,W2] int64
+ * (device memory, capacity in elements), from the epilogue of the layer that writes `seg` while its tile is still in LDS.
+ * kp2d_post with seg = NULL and seg_ids = that buffer then leaves the ids as they are instead of reading `seg` again.
+ * ids = NULL switches it off.  Only valid while `seg` is unchanged between the two calls (the Python host checks the
+ * tensor's identity and version counter). */
+int kp2d_set_seg_ids(kp2d_model* m, int64_t* ids, size_t capacity);
 /* frames per internal sub-batch (0 = automatic).  Intermediates of one sub-batch stay in the 256 MB Infinity Cache. */
 int kp2d_set_chunk_frames(kp2d_model* m, int frames);
 /* Tuning knobs of the engine (never needed for correct results; used by the A/B scripts and the parity tests to force a

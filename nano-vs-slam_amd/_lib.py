@@ -98,6 +98,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kp2d_set_chunk_frames": (C.c_int, [_P, C.c_int]),
     "kp2d_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
+    "kp2d_set_seg_ids": (C.c_int, [_P, _P, C.c_size_t]),
     "kp2d_set_precision": (C.c_int, [_P, C.c_int]),
     "kp2d_get_precision": (C.c_int, [_P]),
     "kp2d_set_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),

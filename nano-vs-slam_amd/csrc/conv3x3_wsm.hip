@@ -82,23 +82,34 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   const int n_my = (nitems - off + G - 1) / G;      // >= 1: the launcher keeps G <= nitems
   const int nsteps = n_my * nchunk;
   const int nsteps_p = wsm_padded_steps(nsteps);
-  // item j -> (tile u = j / groups, group j % groups); tiles of the LAST tile row come last (they are the cheap ones on
-  // maps with a ragged last row, so that the static schedule ends on them everywhere)
+  // item j -> (tile u = j / groups, group j % groups).  Tile order: the cheap tiles come LAST, so that the static schedule
+  // (workgroup w walks items w, w + G, ...) ends on them everywhere instead of handing some workgroups only full tiles
+  // and others only half ones (with G = 96 and three tile columns, the third half empty, a third of the workgroups had
+  // half the work of the rest).  A tile is cheap when half of its waves idle: the last tile column when at most 16 of
+  // its 32 pixel columns exist, the last tile row when at most 8 of its 16 rows exist.  Order: [tiles in neither],
+  // [last column, rows above the last row], [last row].
   const int tx_n = a.tiles_x, ty_n = a.tiles_y;
-  const int per_full = tx_n * (ty_n - 1), nfull = per_full * a.B;
+  const int cc = (W - (tx_n - 1) * M_TW <= 16 && tx_n > 1) ? 1 : 0;
+  const int rr = (H - (ty_n - 1) * M_TH <= 8 && ty_n > 1) ? 1 : 0;
+  const int per_a = (ty_n - rr) * (tx_n - cc), n_a = per_a * a.B;      // per_a >= 1
+  const int per_b = cc * (ty_n - rr), n_b = per_b * a.B;
   auto decode = [&](int i) -> WsmItem {
     const int j = i * G + off;
-    const int u = j / groups;
+    int u = j / groups;
     WsmItem r;
     r.g = j - u * groups;
-    if (u < nfull) {
-      r.b = u / per_full;
-      const int q = u - r.b * per_full, ty = q / tx_n;
-      r.y0 = ty * M_TH; r.x0 = (q - ty * tx_n) * M_TW;
+    if (u < n_a) {
+      r.b = u / per_a;
+      const int q = u - r.b * per_a, ty = q / (tx_n - cc);
+      r.y0 = ty * M_TH; r.x0 = (q - ty * (tx_n - cc)) * M_TW;
+    } else if (u < n_a + n_b) {
+      u -= n_a;
+      r.b = u / per_b;
+      r.y0 = (u - r.b * per_b) * M_TH; r.x0 = (tx_n - 1) * M_TW;
     } else {
-      const int v = u - nfull;
-      r.b = v / tx_n;
-      r.y0 = (ty_n - 1) * M_TH; r.x0 = (v - r.b * tx_n) * M_TW;
+      u -= n_a + n_b;
+      r.b = u / tx_n;
+      r.y0 = (ty_n - 1) * M_TH; r.x0 = (u - r.b * tx_n) * M_TW;
     }
     return r;
   };
@@ -430,10 +441,14 @@ static bool wsm_eligible(const ConvArgs& a) {
 }
 
 // Policy.  A workgroup of this form fills its CU's LDS, so launches of two stream lanes can only run side by side on
-// DISJOINT CUs: with L lanes a launch takes at most CUs / L workgroups (kp2d_api.cpp passes L; a profiling forward runs
-// one lane and takes the whole chip).  The form is used when a launch has at least one work item per workgroup of
-// that grid.  Overrides: ConvArgs::wsm_min / wsm_grid (kp2d_set_option), else KP2D_WSM (0 = never, N = least items) and
-// KP2D_WSM_GRID.
+// DISJOINT CUs: with L lanes a launch takes at most cap = CUs / L workgroups (kp2d_api.cpp passes L; a profiling forward
+// runs one lane and takes the whole chip).  The form is used when a launch has more than TWO rounds of work items for that
+// grid — at one item per workgroup nothing is left to overlap and the general kernels are as fast or faster (30 x 40 maps:
+// 0.031 / 0.047 ms general against 0.032 / 0.052 ms, profiles/r4_layers_wsm_vs_general.txt) — and the grid is sized for whole rounds:
+// rounds = ceil(items / cap), grid = ceil(items / rounds) rounded up to a multiple of 8 (192 items on a cap of 128 run
+// as 2 rounds on 96 workgroups, not 1.5 rounds on 128: the first automatic policy lost 5 % at 32 frames and 20 % at
+// 120 x 160 frames that way, profiles/r4_sweep_first_policy.jsonl).  Overrides: ConvArgs::wsm_min / wsm_grid
+// (kp2d_set_option), else KP2D_WSM (0 = never, N = least items) and KP2D_WSM_GRID.
 int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s) {
   static const long min_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : -1;      // -1: automatic
   static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;
@@ -450,9 +465,17 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s) {
   int cap = a.wsm_grid > 0 ? a.wsm_grid : (grid_env > 0 ? grid_env : cus / lanes);
   if (cap > cus) cap = cus;
   cap &= ~7;                                                   // a multiple of 8: contiguous runs per XCD
-  const long min_items = a.wsm_min > 0 ? a.wsm_min : (min_env > 0 ? min_env : cap);
+  const bool automatic = a.wsm_min == 0 && min_env < 0;
+  // automatic: at least three rounds of work per workgroup (the form's start-up — two steps of loads before the first
+  // product — and its drain are paid per launch: at 32 frames, 192 items per lane, it lost 7 % end to end) and at least
+  // four chunks per item (conv3b, two chunks and two stores per item, is slower in this form: 0.165 against 0.157 ms)
+  const long min_items = a.wsm_min > 0 ? a.wsm_min : (min_env > 0 ? min_env : 2 * cap + 1);
   if (cap < 8 || nitems < min_items || nitems >= (1L << 30)) return -1000;
-  const int grid = (int)(nitems < cap ? nitems : cap) & ~7;
+  if (automatic && a.cin < 64) return -1000;
+  const long rounds = (nitems + cap - 1) / cap;
+  int grid = (int)(((nitems + rounds - 1) / rounds + 7) & ~7L);
+  if (grid > cap) grid = cap;
+  if (grid > nitems) grid = (int)(nitems & ~7L);
   if (grid < 8) return -1000;
   const void* fn = a.store == ST_NHWC ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC>)
                  : a.store == ST_SHUFFLE ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_SHUFFLE>)

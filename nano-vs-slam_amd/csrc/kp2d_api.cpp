@@ -152,6 +152,8 @@ struct kp2d_model {
   std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
   bool profiling = false;
+  int64_t* seg_ids_dst = nullptr;   // kp2d_set_seg_ids: class ids [B,1,H2,W2] written by the forward's last segmentation layer
+  size_t seg_ids_cap = 0;
   std::string tap_name;   // kp2d_set_tap: one intermediate activation copied out (planar) during forward
   float* tap_dst = nullptr;
   size_t tap_cap = 0;
@@ -576,6 +578,8 @@ struct Plan {
   bool dry = false;       // only size the arena
   int B, H, W;
   int b0 = 0;             // first frame of this sub-batch in the caller's batch
+  const float* seg_ptr = nullptr;   // this sub-batch's slice of the caller's seg output and of the class-id map
+  long long* seg_ids = nullptr;     // (kp2d_set_seg_ids): the layer that writes seg also writes its per-pixel argmax
   int nlanes = 1;         // stream lanes of this forward (conv3x3_wsm.hip sizes its grid by it)
   int rc = KP2D_OK;
 
@@ -641,6 +645,7 @@ struct Plan {
     const bool split = m->precision == KP2D_PREC_F16X3;
     { static const int dbg = getenv("KP2D_DBG") ? atoi(getenv("KP2D_DBG")) : 0; a.dbg = dbg; }
     a.prec = split ? 1 : 0;
+    a.ids_out = (store == ST_NCHW && seg_ids && out0 && out0 == seg_ptr && nsplit == c.cout && c.npad == 32) ? seg_ids : nullptr;
     a.wsm_min = m->wsm_min;
     a.wsm_grid = m->wsm_grid;
     a.ws_min = m->ws_min;
@@ -1261,6 +1266,8 @@ static int forward_impl(kp2d_model* m, const float* x, const uint8_t* frames, in
   int rc = validate_shape(m, B, H, W);
   if (rc != KP2D_OK) return rc;
   if ((uintptr_t)workspace % ALIGN) return fail(KP2D_ERR_WORKSPACE, "workspace must be %zu-byte aligned", ALIGN);
+  if (m->seg_ids_dst && !only_enc && m->seg_ids_cap < (size_t)B * (2 * (H >> m->cfg.downsample)) * (2 * (W >> m->cfg.downsample)))
+    return fail(KP2D_ERR_ARG, "kp2d_set_seg_ids: buffer of %zu ids is too small for this forward", m->seg_ids_cap);
   int nl, chunk;
   schedule(m, B, H, W, &nl, &chunk);
   const size_t per = align_up(plan_bytes(m, chunk, H, W));
@@ -1303,6 +1310,8 @@ static int forward_impl(kp2d_model* m, const float* x, const uint8_t* frames, in
     o.shift = shift ? shift + (size_t)b0 * 2 * Hc * Wc : nullptr;
     o.feat = feat ? feat + (size_t)b0 * g.nfeatures * H2 * W2 : nullptr;
     o.seg = seg ? seg + (size_t)b0 * g.n_classes * H2 * W2 : nullptr;
+    P.seg_ptr = o.seg;
+    P.seg_ids = (m->seg_ids_dst && o.seg && !only_enc) ? reinterpret_cast<long long*>(m->seg_ids_dst) + (size_t)b0 * H2 * W2 : nullptr;
     o.vlad = vlad + (size_t)b0 * (only_enc ? (size_t)g.encoder_dim * Hc * Wc : kp2d_vlad_dim(m, H, W));
     o.depth = depth ? depth + (size_t)b0 * H2 * W2 : nullptr;
     build(P, o, flags);
@@ -1340,7 +1349,9 @@ int kp2d_post(kp2d_model* m, const float* score, const float* shift, const float
               float* coord, float* desc, int64_t* seg_ids, int sample_segmentation, void* stream) {
   if (!m || !score || !shift || !score_out || !coord) return fail(KP2D_ERR_ARG, "null argument");
   if (desc && !feat) return fail(KP2D_ERR_ARG, "desc requested without feat");
-  if (seg_ids && !seg) return fail(KP2D_ERR_ARG, "seg_ids requested without seg");
+  // seg == NULL with seg_ids: the ids are already there (the forward wrote them, kp2d_set_seg_ids) and are left alone
+  if (seg_ids && !seg && sample_segmentation) return fail(KP2D_ERR_ARG, "sampled class ids need the seg tensor");
+  if (seg_ids && !seg) seg_ids = nullptr;
   DeviceGuard guard(m->cfg.device);
   PostArgs a{};
   a.score_in = score; a.shift = shift; a.feat = feat; a.score_out = score_out; a.coord = coord; a.desc = desc;
@@ -1550,6 +1561,13 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
     return KP2D_OK;
   }
   return fail(KP2D_ERR_ARG, "unknown option '%s'", key);
+}
+
+int kp2d_set_seg_ids(kp2d_model* m, int64_t* ids, size_t capacity) {
+  if (!m) return fail(KP2D_ERR_ARG, "null model");
+  m->seg_ids_dst = ids;
+  m->seg_ids_cap = ids ? capacity : 0;
+  return KP2D_OK;
 }
 
 int kp2d_set_chunk_frames(kp2d_model* m, int frames) {

@@ -47,6 +47,7 @@ struct ConvArgs {
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
   int wsm_min;                        // least (tile, group) work items for the warp-specialised multi-chunk form; 0: automatic (KP2D_WSM, else one per workgroup); < 0: never
   int wsm_lanes;                      // stream lanes launching side by side (the form takes CUs / lanes workgroups)
+  long long* ids_out;                 // ST_NCHW, one channel group: also write argmax over the stored channels per pixel, [B][H][W] int64 (nullptr: no)
   int ws_min;                         // least tiles for the warp-specialised conv1b form (0: 1024)
   int wsm_grid;                       // most workgroups of that form per launch; 0: KP2D_WSM_GRID or one per CU
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores

@@ -20,6 +20,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import inspect
+import weakref
 import os
 
 import torch
@@ -527,6 +528,25 @@ class _KP2DTinyBase(nn.Module):
         ws = eng.workspace(B, H, W, dev)
         flags = 0 if self.training else _lib.KP2D_FWD_EVAL
         stream = torch.cuda.current_stream(dev).cuda_stream
+        # inference mode: the layer that writes `seg` also writes the dense class map post_processing starts with (its
+        # tile of logits is in LDS anyway), so post_processing need not read the logits again — if it gets THIS tensor,
+        # unmodified (see post_processing)
+        ids = None
+        if not self.training and not self.sample_segmentation and os.environ.get("KP2D_FUSED_ARGMAX", "1") != "0":
+            ids = torch.empty(B, 1, H2, W2, dtype=torch.int64, device=dev)
+            _lib.check(eng.lib.kp2d_set_seg_ids(eng.handle, _ptr(ids), ids.numel()))
+        try:
+            self._run_forward(eng, x, frames, B, H, W, flags, score, shift, feat, seg, vlad, depth, ws, stream)
+        finally:
+            if ids is not None:
+                eng.lib.kp2d_set_seg_ids(eng.handle, None, 0)
+        self.__dict__["_seg_ids_cache"] = (weakref.ref(seg), seg._version, ids) if ids is not None else None
+        out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
+        if self.depth:
+            out["depth"] = depth        # already sigmoid (kp2dtiny.py:588-590 / :955-956)
+        return out
+
+    def _run_forward(self, eng, x, frames, B, H, W, flags, score, shift, feat, seg, vlad, depth, ws, stream):
         if frames is None:
             _lib.check(eng.lib.kp2d_forward(eng.handle, _ptr(x), B, H, W, flags, _ptr(score), _ptr(shift), _ptr(feat),
                                             _ptr(seg), _ptr(vlad), _ptr(depth), _ptr(ws), ws.numel(), C.c_void_p(stream)))
@@ -534,10 +554,6 @@ class _KP2DTinyBase(nn.Module):
             _lib.check(eng.lib.kp2d_forward_frames(eng.handle, _ptr(frames), B, frames.shape[1], frames.shape[2], H, W, flags,
                                                    _ptr(score), _ptr(shift), _ptr(feat), _ptr(seg), _ptr(vlad), _ptr(depth),
                                                    _ptr(ws), ws.numel(), C.c_void_p(stream)))
-        out = {"score": score, "coord": shift, "feat": feat, "vlad": vlad, "seg": seg}
-        if self.depth:
-            out["depth"] = depth        # already sigmoid (kp2dtiny.py:588-590 / :955-956)
-        return out
 
     def post_processing(self, out, H, W):
         """Reference: post_processing kp2dtiny.py:593-625 / :959-993 (mutates and returns ``out``)."""
@@ -558,8 +574,15 @@ class _KP2DTinyBase(nn.Module):
             seg = out["seg"].contiguous()
             sc, Hs, Ws = seg.shape[1], seg.shape[2], seg.shape[3]
             desc = torch.empty(B, fc, Hc, Wc, device=dev)
-            seg_ids = (torch.empty(B, 1, Hc, Wc, dtype=torch.int64, device=dev) if self.sample_segmentation
-                       else torch.empty(B, 1, Hs, Ws, dtype=torch.int64, device=dev))
+            # class ids the forward already wrote (kp2d_set_seg_ids) are taken over when `seg` is the very tensor that
+            # forward returned, untouched since (same object, same version counter); any other dict goes the full way
+            cache = self.__dict__.pop("_seg_ids_cache", None)
+            if (cache is not None and not self.sample_segmentation and cache[0]() is out["seg"] and seg is out["seg"]
+                    and seg._version == cache[1] and tuple(cache[2].shape) == (B, 1, Hs, Ws)):
+                seg_ids, seg = cache[2], None
+            else:
+                seg_ids = (torch.empty(B, 1, Hc, Wc, dtype=torch.int64, device=dev) if self.sample_segmentation
+                           else torch.empty(B, 1, Hs, Ws, dtype=torch.int64, device=dev))
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(eng.lib.kp2d_post(eng.handle, _ptr(score), _ptr(shift), _ptr(feat), _ptr(seg), B, int(H), int(W),
                                      Hc, Wc, fc, Hf, Wf, sc, Hs, Ws, _ptr(score_out), _ptr(coord), _ptr(desc),
