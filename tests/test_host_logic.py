@@ -1,7 +1,11 @@
 """Host-side mirror of the reference's model API (no GPU needed)."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+from conftest import ROOT
 
 from nano_vs_slam_amd.kp2dtiny.models import kp2dtiny as K
 from nano_vs_slam_amd.sharding import shard_range
@@ -169,3 +173,45 @@ def test_lightglue_host_mirror_layout_and_no_cpu_path():
         m(data)                                      # CPU tensors: refused, never a fallback
     with pytest.raises(RuntimeError):
         m.transformers[0].self_attn(torch.zeros(1, 8, 32))
+
+
+def test_warp_specialised_conv_kernels_compile_without_spills_and_keep_their_counted_wait(tmp_path):
+    """conv3x3_wsm.hip rests on two properties of the generated code that no run-time test sees directly:
+    (1) no VGPR spills — a spill inside the matrix phase costs more than the form gains, and scratch traffic of the
+        staging waves would join the vmcnt queue;
+    (2) the staging loop's counted wait: the nine LDS-DMA pieces of a weight slab are issued BEFORE the ten loads of the
+        next request and `s_waitcnt vmcnt(10)` stands in front of the step's barrier (newer operations only make that
+        wait stronger; fewer than ten newer ones would let a barrier pass with a slab still in flight).
+    Cross-compiles the file for gfx950 (no GPU needed) and reads the assembly."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = os.path.join(ROOT, "nano-vs-slam_amd", "csrc", "conv3x3_wsm.hip")
+    out = tmp_path / "wsm.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-I" + os.path.join(ROOT, "nano-vs-slam_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), src, "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    asm = out.read_text()
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
+    vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", asm)]
+    assert len(spills) == 4 and all(s == 0 for s in spills), spills          # one instantiation per store mode
+    assert all(v <= 168 for v in vgprs), vgprs                               # three waves per SIMD (768 threads per CU)
+    kernels = asm.split("s_endpgm")
+    checked = 0
+    for body in kernels:
+        if "buffer_load_dwordx4" not in body or " lds" not in body:
+            continue
+        lines = [ln.strip() for ln in body.splitlines()]
+        waits = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt vmcnt(10)")]
+        assert len(waits) >= 3, len(waits)                                   # prologue + the two half-steps of the loop
+        for w in waits[1:]:
+            # walking back from the wait: ten plain loads, then (further back) the nine LDS-DMA pieces, nothing else of VMEM
+            back = [ln for ln in lines[:w] if ln.startswith("buffer_") or ln.startswith("global_") or ln.startswith("scratch_")]
+            tail = back[-19:]
+            assert all("lds" not in ln for ln in tail[-10:]), tail[-10:]
+            assert all(ln.endswith("lds") for ln in tail[:9]), tail[:9]
+        checked += 1
+    assert checked == 4
