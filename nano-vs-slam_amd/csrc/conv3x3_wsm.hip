@@ -118,6 +118,10 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   // (experiment: start the workgroups out of step — every CU otherwise reaches its items' store bursts together)
   if (KP2D_DBG_ON(1024)) for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(33);
   if (KP2D_DBG_ON(2048)) for (int i = 0; i < (int)(blockIdx.x & 3); ++i) __builtin_amdgcn_s_sleep(100);
+  // (blockIdx.x & 7 is the XCD: the two skews above shift whole XCDs against each other.  Within an XCD — whose L2 and
+  // fabric port take the 32 CUs' item stores — neighbours are blockIdx.x >> 3:)
+  if (KP2D_DBG_ON(8192)) for (int i = 0; i < 2 * (int)((blockIdx.x >> 3) & 1); ++i) __builtin_amdgcn_s_sleep(115);      // half of the CUs ~7 us late
+  if (KP2D_DBG_ON(16384)) for (int i = 0; i < (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(58);           // quarters, ~1.75 us apart
 #endif
   // per-channel scale | shift of the whole layer -> LDS (the multiplying waves read 4 channels per ds_read_b128)
   for (int c = tid; c < a.npad; c += M_THREADS) {
