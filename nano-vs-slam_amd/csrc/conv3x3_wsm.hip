@@ -371,12 +371,14 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       const int s1 = (a.oo1 + cn) * 4;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = fmaf(acc[m][n][r], sc[r], sh[r]);
-          v[r] = fmaxf(t, t * slope);
-        }
+        // scale / shift and the slope product two values per instruction (v_pk_fma_f32 / v_pk_mul_f32: same fused
+        // arithmetic as fmaf / *, half the issue slots — no MFMA of this wave or of its SIMD partner is in flight here)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 a01 = {acc[m][n][0], acc[m][n][1]}, a23 = {acc[m][n][2], acc[m][n][3]};
+        const f32x2 t01 = __builtin_elementwise_fma(a01, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+        const f32x2 t23 = __builtin_elementwise_fma(a23, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+        const f32x2 u01 = t01 * slope, u23 = t23 * slope;
+        const f32x4 v = {fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1]), fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
         if (full) {
 #ifdef KP2D_ABLATE
           if (KP2D_DBG_ON(4096)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0, (vo[m] + s0) | cinv, 0, 2);      // (experiment: nt)
