@@ -564,7 +564,12 @@ int launch_gather(const GatherArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(gather_lds_kernel<8>, dim3(a.C / 8, a.B), block, (size_t)a.n * 8 * 4, s, a);
       return (int)hipGetLastError();
     }
-    if ((long)a.n * 4 * 4 <= 65536) {
+    // Four planes per workgroup keep the 16-byte stores of a keypoint's row; past 64 KB that takes the opt-in to the
+    // CU's whole LDS (4800 cells at 240 x 320: 76.8 KB, two workgroups per CU).  Two planes per workgroup wrote 8 bytes
+    // per keypoint from sixteen workgroups per frame: 30 us at 64 frames.
+    if ((long)a.n * 4 * 4 <= 80 * 1024) {
+      static PerDeviceOnce lds_once;
+      if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&gather_lds_kernel<4>))) return e;
       hipLaunchKernelGGL(gather_lds_kernel<4>, dim3(a.C / 4, a.B), block, (size_t)a.n * 4 * 4, s, a);
       return (int)hipGetLastError();
     }
