@@ -15,6 +15,8 @@
 //   pairs_kernel    compacts the matched rows of a pair into (x0, y0, x1, y1) / (q, t) / distance lists (train order)
 // Batched over B frame pairs with per-pair descriptor counts, so the per-frame D2H copy + CPU matcher of the
 // reference disappears.  HBM-light (descriptors are tiny); bound by VALU: n0*n1*C*3 ops per pair.
+#include <cstdlib>
+
 #include "kp2d_kernels.h"
 
 namespace kp2d {
@@ -103,6 +105,169 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ d0,
     nn_idx[o] = bi;
     nn_dist[o] = best;
     if (nn_dist2) nn_dist2[o] = second;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same search with the distances on the matrix cores (round 4).  The VALU kernel above spends ~70 instructions per
+// (query, train) pair; here a 32 x 32 block of dot products is 3 C / 16 MFMAs (split-fp16 operands: q = qh + ql, t = th + tl,
+// q.t = qh.th + qh.tl + ql.th on v_mfma_f32_32x32x16_f16, fp32 accumulation: error ~1e-7 |q||t|) and a pair costs nine VALU
+// instructions (key = |t|^2 - 2 q.t, then a running best / second WITH indices).  The approximate keys only RANK: every
+// query's final answer comes from an exact pass — the candidates (best and second of each of the query's two lanes, four
+// per query) are re-evaluated with the arithmetic of the VALU kernel, sqrt(sum_c fma(d, d, .)) in channel order, and the
+// nearest / second-nearest are taken by (exact distance, lower index).  So nn_dist / nn_dist2 are bit-identical to the
+// VALU kernel's, and nn_idx differs from it only if three train rows of one lane's half lie within ~1e-6 of each other
+// without being identical (identical rows have identical keys and keep their index order).
+// A workgroup = four waves x 32 queries against the same LDS tiles of train rows.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 mh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 mh2 __attribute__((ext_vector_type(2)));
+typedef float mf16 __attribute__((ext_vector_type(16)));
+typedef float mf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void m_split4(const float4 v, mh4& hi, mh4& lo) {      // (as netvlad.hip vlad_split4)
+  const mf2 a = {v.x, v.y}, b = {v.z, v.w};
+  const mh2 ha = __builtin_convertvector(a, mh2), hb = __builtin_convertvector(b, mh2);
+  unsigned la, lb;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(ha), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(la) : "v"(ha), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v.w));
+  const mh2 l0 = __builtin_bit_cast(mh2, la), l1 = __builtin_bit_cast(mh2, lb);
+  hi = mh4{ha[0], ha[1], hb[0], hb[1]};
+  lo = mh4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+constexpr int MM_Q = 128;                                    // queries per workgroup
+__host__ __device__ constexpr int mm_rows(int C) { return C >= 128 ? 64 : 128; }      // train rows per LDS fill
+
+template <int C, bool MASKED>
+__global__ __launch_bounds__(256) void knn2_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
+                                                        const int32_t* __restrict__ n0p, const int32_t* __restrict__ n1p,
+                                                        const int32_t* __restrict__ c0, const int32_t* __restrict__ c1,
+                                                        int max0, int max1, int32_t* __restrict__ nn_idx,
+                                                        float* __restrict__ nn_dist, float* __restrict__ nn_dist2,
+                                                        unsigned long long* __restrict__ init_best, long init_n) {
+  constexpr int MT = mm_rows(C), HP = C + 8, KS = C / 16;    // LDS row pitch in halves (16 bytes of padding), k-steps
+  __shared__ __attribute__((aligned(16))) _Float16 s_h[MT * HP];
+  __shared__ __attribute__((aligned(16))) _Float16 s_l[MT * HP];
+  __shared__ __attribute__((aligned(16))) float s_n[MT];
+  __shared__ int s_c[MT];
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions past the fp16 range clamp (ranking only)
+  if (init_best) {
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (long e = wg * 256 + threadIdx.x; e < init_n; e += (long)gridDim.x * gridDim.y * gridDim.z * 256) init_best[e] = ~0ull;
+  }
+  const int b = blockIdx.y;
+  const int n0 = n0p[b], n1 = n1p[b];
+  if (blockIdx.x * MM_Q >= n0) return;               // whole workgroup out of range (uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int q = blockIdx.x * MM_Q + wave * 32 + j;   // this lane's query (both lane halves hold it)
+  const int nz = gridDim.z, z = blockIdx.z;
+  const int tiles = (n1 + MT - 1) / MT, per = (tiles + nz - 1) / nz;
+  const int t_lo = min(n1, z * per * MT), t_hi = min(n1, (z + 1) * per * MT);
+  const float* qp = d0 + ((size_t)b * max0 + (q < n0 ? q : 0)) * C;
+  // B operand: lane (j, h) holds channels 16 s + 8 h .. + 7 of its query, hi and lo halves, for every k-step
+  mh8 qh[KS], ql[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * h), v1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * h + 4);
+    mh4 h0, l0, h1, l1;
+    m_split4(v0, h0, l0);
+    m_split4(v1, h1, l1);
+    qh[s] = mh8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    ql[s] = mh8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  }
+  const int qc = MASKED ? c0[(size_t)b * max0 + (q < n0 ? q : 0)] : 0;
+  float best = INFINITY, second = INFINITY;          // approximate keys |t|^2 - 2 q.t of this lane's half of the train rows
+  int bi = -1, si = -1;
+  constexpr int LPR = C / 4;                          // lanes per train row in the staging loop (a float4 each)
+  for (int t0 = t_lo; t0 < t_hi; t0 += MT) {
+    const int nt = min(MT, t_hi - t0);
+    __syncthreads();
+    for (int e = tid; e < MT * LPR; e += 256) {
+      const int row = e / LPR, c4 = e - row * LPR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nt) v = reinterpret_cast<const float4*>(d1 + ((size_t)b * max1 + t0) * C)[e];
+      mh4 hi, lo;
+      m_split4(v, hi, lo);
+      *reinterpret_cast<mh4*>(&s_h[row * HP + 4 * c4]) = hi;
+      *reinterpret_cast<mh4*>(&s_l[row * HP + 4 * c4]) = lo;
+      float nn = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) nn += __shfl_xor(nn, o);
+      if (c4 == 0) {
+        s_n[row] = row < nt ? nn : INFINITY;          // rows past the range can never be a neighbour
+        if (MASKED) s_c[row] = row < nt ? c1[(size_t)b * max1 + t0 + row] : -1;
+      }
+    }
+    __syncthreads();
+    for (int tt = 0; tt < MT; tt += 32) {
+      if (tt >= nt) break;
+      mf16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const _Float16* th = &s_h[(tt + j) * HP + 8 * h];
+      const _Float16* tl = &s_l[(tt + j) * HP + 8 * h];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const mh8 ah = *reinterpret_cast<const mh8*>(th + 16 * s), al = *reinterpret_cast<const mh8*>(tl + 16 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], acc, 0, 0, 0);
+      }
+      // accumulator register r of lane (j, h): train row tt + (r & 3) + 8 (r >> 2) + 4 h, ascending in r
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 tn = *reinterpret_cast<const float4*>(&s_n[tt + 8 * g + 4 * h]);
+        const float tnv[4] = {tn.x, tn.y, tn.z, tn.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = tt + 8 * g + 4 * h + u;
+          float key = fmaf(-2.f, acc[4 * g + u], tnv[u]);
+          if (MASKED && s_c[row] != qc) key = INFINITY;
+          const bool lt1 = key < best, lt2 = key < second;
+          si = lt1 ? bi : (lt2 ? t0 + row : si);
+          second = lt1 ? best : (lt2 ? key : second);
+          bi = lt1 ? t0 + row : bi;
+          best = lt1 ? key : best;
+        }
+      }
+    }
+  }
+  // ---- exact pass: this lane's two candidates with the VALU kernel's arithmetic ----
+  auto exact = [&](int t) -> float {
+    if (t < 0) return INFINITY;
+    const float* tp = d1 + ((size_t)b * max1 + t) * C;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) { const float d = qp[c] - tp[c]; acc = fmaf(d, d, acc); }
+    return sqrtf(acc);
+  };
+  if (!(best < INFINITY)) bi = -1;                    // (masked-out / empty ranges leave +inf keys with stale indices)
+  if (!(second < INFINITY)) si = -1;
+  float e1 = exact(bi), e2 = exact(si);
+  int i1 = bi, i2 = si;
+  auto before = [](float da, int ia, float db, int ib) { return ib < 0 || (ia >= 0 && (da < db || (da == db && ia < ib))); };
+  if (!before(e1, i1, e2, i2)) { const float te = e1; e1 = e2; e2 = te; const int ti = i1; i1 = i2; i2 = ti; }
+  // merge with the other half of the train rows (lane ^ 32): two sorted pairs -> the two smallest by (distance, index)
+  const float f1 = __shfl_xor(e1, 32), f2 = __shfl_xor(e2, 32);
+  const int k1 = __shfl_xor(i1, 32), k2 = __shfl_xor(i2, 32);
+  float rb, rs; int ri;
+  if (before(e1, i1, f1, k1)) {
+    rb = e1; ri = i1;
+    rs = before(e2, i2, f1, k1) ? e2 : f1;
+  } else {
+    rb = f1; ri = k1;
+    rs = before(f2, k2, e1, i1) ? f2 : e1;
+  }
+  if (h == 0 && q < n0) {
+    const size_t o = ((size_t)z * gridDim.y + b) * max0 + q;
+    nn_idx[o] = ri;
+    nn_dist[o] = ri >= 0 ? rb : INFINITY;
+    if (nn_dist2) nn_dist2[o] = rs;
   }
 }
 
@@ -210,8 +375,14 @@ __global__ __launch_bounds__(256) void match_pairs_kernel(const PairsArgs a) {
 
 template <int C>
 static void launch_knn2(const float* d0, const float* d1, const int32_t* n0, const int32_t* n1, const int32_t* c0,
-                        const int32_t* c1, int B, int max0, int max1, int nz, int32_t* idx, float* dist, float* dist2,
+                        const int32_t* c1, int B, int max0, int max1, int nz, bool mfma, int32_t* idx, float* dist, float* dist2,
                         unsigned long long* init_best, long init_n, hipStream_t s) {
+  if (mfma) {
+    dim3 g((max0 + MM_Q - 1) / MM_Q, B, nz);
+    if (c0) hipLaunchKernelGGL((knn2_mfma_kernel<C, true>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
+    else hipLaunchKernelGGL((knn2_mfma_kernel<C, false>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
+    return;
+  }
   dim3 g((max0 + MQ - 1) / MQ, B, nz);
   if (c0) hipLaunchKernelGGL((knn2_kernel<C, true>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
   else hipLaunchKernelGGL((knn2_kernel<C, false>), g, dim3(256), 0, s, d0, d1, n0, n1, c0, c1, max0, max1, idx, dist, dist2, init_best, init_n);
@@ -228,10 +399,15 @@ static int knn2(const MatchArgs& a, bool reverse, int32_t* idx, float* dist, flo
   const int32_t* c0 = reverse ? a.cls1 : a.cls0;
   const int32_t* c1 = reverse ? a.cls0 : a.cls1;
   const int max0 = reverse ? a.max1 : a.max0, max1 = reverse ? a.max0 : a.max1;
-  const long wgs = (long)((max0 + MQ - 1) / MQ) * a.B;
+  // matrix-core form from 256 train rows (below that a query meets one or two LDS tiles and the exact pass dominates);
+  // KP2D_MATCH_MFMA=0: always the VALU form (A/B)
+  static const bool mfma_on = !(getenv("KP2D_MATCH_MFMA") && getenv("KP2D_MATCH_MFMA")[0] == '0');
+  const bool mfma = mfma_on && max1 >= 256;
+  const int qpw = mfma ? MM_Q : MQ, rows = mfma ? mm_rows(a.C) : mt_rows(a.C);
+  const long wgs = (long)((max0 + qpw - 1) / qpw) * a.B;
   int nz = 1;
   if (a.part_idx && wgs < 512) {
-    const int tiles = (max1 + mt_rows(a.C) - 1) / mt_rows(a.C);
+    const int tiles = (max1 + rows - 1) / rows;
     nz = (int)((1024 + wgs - 1) / wgs);
     if (nz > tiles) nz = tiles;
     if (nz > a.part_slices) nz = a.part_slices;
@@ -243,9 +419,9 @@ static int knn2(const MatchArgs& a, bool reverse, int32_t* idx, float* dist, flo
   unsigned long long* ib = assign ? a.train_best : nullptr;
   const long in = (long)a.B * a.max1;
   switch (a.C) {
-    case 32: launch_knn2<32>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
-    case 64: launch_knn2<64>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
-    case 128: launch_knn2<128>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, o_idx, o_d, o_d2, ib, in, s); break;
+    case 32: launch_knn2<32>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, mfma, o_idx, o_d, o_d2, ib, in, s); break;
+    case 64: launch_knn2<64>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, mfma, o_idx, o_d, o_d2, ib, in, s); break;
+    case 128: launch_knn2<128>(d0, d1, n0, n1, c0, c1, a.B, max0, max1, nz, mfma, o_idx, o_d, o_d2, ib, in, s); break;
     default: return -1500;
   }
   if (assigned) *assigned = false;

@@ -1179,6 +1179,15 @@ def test_descriptor_matching_widths_and_sliced_search(C):
         assert np.max(np.abs(r["nn_dist"][b, :n0[b]].cpu().numpy() - dd1)) < 2e-5
         n = _pairs_equal(r["match_q"][b].cpu().numpy(), best, dd1, dd2, 0.7)
         assert n > 100 or b > 0
+    # fewer than 256 train rows: the VALU form of the search (the matrix-core form serves the sets above)
+    ks = 200
+    rs = match_descriptors(t(d0), t(n0), t(np.ascontiguousarray(d1[:, :ks])), t(np.minimum(n1, ks)), 0.7)
+    for b in range(B):
+        nb = min(int(n1[b]), ks)
+        best, nn, dd1, dd2 = orc.bf_match_one_to_one(d0[b, :n0[b]], d1[b, :nb], 0.7)
+        assert np.array_equal(rs["nn_idx"][b, :n0[b]].cpu().numpy(), nn)
+        assert np.max(np.abs(rs["nn_dist"][b, :n0[b]].cpu().numpy() - dd1)) < 2e-5
+        _pairs_equal(rs["match_q"][b].cpu().numpy(), best, dd1, dd2, 0.7)
 
 
 def test_descriptor_matching_per_class():

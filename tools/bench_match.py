@@ -57,10 +57,15 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / a.reps
         evals = B * k0 * k1 * (2 if kw.get("mutual") else 1)
         lane_ops = evals * 3 * C
-        print(json.dumps({"case": name, "us_per_call": round(us, 2), "pairs_kernel_us": round(e1.elapsed_time(e2) * 1e3 / a.reps, 2),
-                          "gevals_per_s": round(evals / us * 1e-3, 1),
-                          "valu_frac_at_2.4GHz": round(lane_ops / (us * 1e-6) / (256 * 128 * 2.4e9), 3),
-                          "matches_pair0": int(po["count"][0])}), flush=True)
+        mfma = os.environ.get("KP2D_MATCH_MFMA", "1") != "0" and k1 >= 256
+        rec = {"case": name, "form": "matrix cores + exact recheck" if mfma else "VALU", "us_per_call": round(us, 2),
+               "pairs_kernel_us": round(e1.elapsed_time(e2) * 1e3 / a.reps, 2), "gevals_per_s": round(evals / us * 1e-3, 1),
+               "matches_pair0": int(po["count"][0])}
+        if mfma:     # 3 C / 16 MFMAs of 32 x 32 x 16 per 1024 evaluations against the dense fp16 peak
+            rec["mfma_frac_of_2516_TFLOPs"] = round(evals * 3 * C * 2 / (us * 1e-6) / 2516.6e12, 3)
+        else:        # 3 C lane-operations per evaluation against 256 CUs x 128 lanes x 2.4 GHz
+            rec["valu_frac_at_2.4GHz"] = round(lane_ops / (us * 1e-6) / (256 * 128 * 2.4e9), 3)
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
