@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU): pattern of the values that differ in one layer (tap) between the two conv forms."""
+"""Diagnostic (GPU; produced profiles/r4_wsm_store_hazard.txt): pattern of the values that differ in one layer (tap) between the two conv forms."""
 import ctypes as C
 import os
 import sys
