@@ -613,7 +613,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
     // multi-chunk layers with 64-channel groups on grids that fill the chip: warp-specialised persistent form
     // (conv3x3_wsm.hip; policy and overrides at its launcher)
     {
-      const int e = launch_conv3x3_f16x3_wsm(a, s);
+      const int e = launch_conv3x3_f16x3_wsm(a, s, 64);
       if (e != -1000) { g_variant = "<wsm>"; return e; }
     }
     // map heights that leave the last 16-row tile row at most half full (120 = 7.5 x 16): 8 x 32 tiles, no ragged row
@@ -631,6 +631,11 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
       !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= (a.ws_min > 0 ? a.ws_min : 1024) &&
       (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
   { g_variant = "<ws>"; return launch_ws(a, s); }
+  // 32-channel layers on grids that fill the chip several times: the warp-specialised persistent form with 32-channel items
+  if (a.npad == 32 && !a.ng32) {
+    const int e = launch_conv3x3_f16x3_wsm(a, s, 32);
+    if (e != -1000) { g_variant = "<wsm32>"; return e; }
+  }
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);
   // (planar API outputs keep the 16-pixel tiles: measured 0.148 -> 0.151 ms on desc_head.confBb with the wide ones)

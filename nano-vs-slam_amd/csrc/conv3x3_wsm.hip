@@ -37,21 +37,20 @@ namespace {
 constexpr int M_TH = 16, M_TW = 32, M_PITCH = 36, M_ROWS = M_TH + 2, M_COLS = M_TW + 2, M_PXB = 32;
 constexpr int M_LO = M_ROWS * M_PITCH * M_PXB;         // byte offset of an image's lo plane (20,736)
 constexpr int M_IMG = 2 * M_LO;                        // one input image: hi plane | lo plane (41,472 B)
-constexpr int M_N = 64;                                // channels per work item
-constexpr int M_WL = 9 * M_N * 32;                     // byte offset of the wl plane behind the wh plane (18,432)
-constexpr int M_WSLAB = 2 * M_WL;                      // a chunk's weight slab (36,864 B)
-constexpr int M_STAGE = M_IMG + M_WSLAB;               // one stage: image | weights (78,336 B)
-constexpr int M_SS = 2 * M_STAGE;                      // scale | shift vectors behind the two stages (156,672)
+// N = channels per work item: 64 (four 16-channel N-tiles per multiplying wave) or 32 (two; the 32-channel layers)
+__host__ __device__ constexpr int m_wl(int n) { return 9 * n * 32; }                  // byte offset of the wl plane behind the wh plane (18,432 at 64)
+__host__ __device__ constexpr int m_wslab(int n) { return 2 * m_wl(n); }              // a chunk's weight slab (36,864 B)
+__host__ __device__ constexpr int m_stage(int n) { return M_IMG + m_wslab(n); }       // one stage: image | weights (78,336 B)
+__host__ __device__ constexpr int m_ss(int n) { return 2 * m_stage(n); }              // scale | shift vectors behind the two stages (156,672)
 constexpr int M_MAXN = 256;                            // channels of a layer (scale / shift in LDS)
-constexpr int M_LDS = M_SS + 2 * M_MAXN * 4;           // 158,720 B
+__host__ __device__ constexpr int m_lds(int n) { return m_ss(n) + 2 * M_MAXN * 4; }   // 158,720 B / 121,856 B
 constexpr int M_G = M_ROWS * M_COLS * 4;               // 16-byte granules of a halo image (2448)
 constexpr int M_PT = 256;                              // staging threads
 constexpr int M_IT = (M_G + M_PT - 1) / M_PT;          // granules per staging thread (10)
-constexpr int M_PIECES = M_WSLAB / 1024;               // 1-KiB LDS-DMA pieces of a weight slab (36)
-constexpr int M_PW = M_PIECES / 4;                     // per staging wave (9)
+__host__ __device__ constexpr int m_pieces(int n) { return m_wslab(n) / 1024; }       // 1-KiB LDS-DMA pieces of a weight slab (36 / 18)
 constexpr int M_THREADS = 768;
-static_assert(M_PIECES % 4 == 0, "weight slab pieces must divide over the four staging waves");
-static_assert(M_LDS <= 160 * 1024, "LDS budget");
+static_assert(m_wslab(32) % 1024 == 0 && m_wslab(64) % 1024 == 0, "weight slabs are whole 1-KiB pieces");
+static_assert(m_lds(64) <= 160 * 1024, "LDS budget");
 
 __host__ __device__ constexpr int m_slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
 // barriers each role executes for `nsteps` steps (the ONE definition both loops are written against)
@@ -62,8 +61,10 @@ struct WsmItem { int b, y0, x0, g; };
 
 // STORE: the layer's store mode (kp2d_kernels.h::Store) as a template parameter — the pooled path's registers and DPP code
 // exist only in the two instantiations that pool
-template <int STORE>
+template <int STORE, int NN>
 __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const ConvArgs a, const int nitems, const int ntiles) {
+  constexpr int M_N = 16 * NN, M_WL = m_wl(M_N), M_WSLAB = m_wslab(M_N), M_STAGE = m_stage(M_N), M_SS = m_ss(M_N);
+  constexpr int M_PIECES = m_pieces(M_N), M_PW = (M_PIECES + 3) / 4;      // pieces per staging wave: 9, or 5 / 4
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
@@ -215,7 +216,9 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       const int sbase = (dm_g * nchunk + dm_ch) * M_WSLAB;
 #pragma unroll
       for (int j = 0; j < M_PW; ++j) {
-        const int pc = pw + 4 * j;
+        // (18 pieces over four waves: waves 2, 3 copy pieces 0, 1 a second time in their fifth slot — the same bytes to
+        // the same place — so that every wave issues the same straight-line sequence)
+        const int pc = M_PIECES % 4 == 0 ? pw + 4 * j : (pw + 4 * j) % M_PIECES;
         const int plane = pc >= M_WL / 1024 ? 1 : 0, pp = pc - plane * (M_WL / 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + stage * M_STAGE + M_IMG + 1024 * pc),
                                                  16, KP2D_DBG_ON(16) ? OOB : w_lane, sbase + 2048 * pp + 32 * plane, 0, 0);
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   // wave (wr, ph) owns tile rows 4 wr .. 4 wr + 3 x columns 16 ph .. 16 ph + 15 = four M-tiles of 2 x 8 pixels, and all
   // four 16-channel N-tiles.  The second column half's waves take the row groups rotated by two, so the two waves of a
   // SIMD (w and w + 4) differ in rows AND columns: in ragged tiles the waves that still work spread over all four SIMDs.
-  constexpr int MT = 4, NN = 4, CB = 2;
+  constexpr int MT = 4, CB = 2;
   const int lg = lane >> 4, lp = lane & 15;
   const int ph = wave >> 2, wr = (wave + 2 * ph) & 3;
   const int a0 = ((wr * 4 + ((lp >> 1) & 1)) * M_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * M_PXB + 16 * (lg & 1);
@@ -430,8 +433,8 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
 }
 
 // true when the layer can run as the kernel above (launch_conv3x3_f16x3 falls back to the general kernel otherwise)
-static bool wsm_eligible(const ConvArgs& a) {
-  if (a.taps != 9 || a.prec != 1 || a.ng32 || a.npad % M_N != 0 || a.npad > M_MAXN) return false;
+static bool wsm_eligible(const ConvArgs& a, int N) {
+  if (a.taps != 9 || a.prec != 1 || a.ng32 || a.npad % N != 0 || a.npad > M_MAXN) return false;
   if (a.store != ST_NHWC && a.store != ST_SHUFFLE && a.store != ST_NHWC_BOTH && a.store != ST_NHWC_POOL) return false;
   if (a.act > ACT_RELU) return false;
   if (((a.in0.c | a.cin) & 15) != 0 || a.cin < 32) return false;      // whole 16-channel chunks, never straddling the sources
@@ -446,6 +449,23 @@ static bool wsm_eligible(const ConvArgs& a) {
   return true;
 }
 
+template <int STORE, int NN>
+static int wsm_launch_one(const ConvArgs& a, int grid, long nitems, long ntiles, hipStream_t s) {
+  static PerDeviceOnce lds_once;      // per instantiation and device
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<STORE, NN>))) return e;
+  hipLaunchKernelGGL((conv3x3_f16x3_wsm_kernel<STORE, NN>), dim3(grid), dim3(M_THREADS), m_lds(16 * NN), s, a, (int)nitems, (int)ntiles);
+  return (int)hipGetLastError();
+}
+template <int NN>
+static int wsm_launch(const ConvArgs& a, int grid, long nitems, long ntiles, hipStream_t s) {
+  switch (a.store) {
+    case ST_NHWC: return wsm_launch_one<ST_NHWC, NN>(a, grid, nitems, ntiles, s);
+    case ST_SHUFFLE: return wsm_launch_one<ST_SHUFFLE, NN>(a, grid, nitems, ntiles, s);
+    case ST_NHWC_BOTH: return wsm_launch_one<ST_NHWC_BOTH, NN>(a, grid, nitems, ntiles, s);
+    default: return wsm_launch_one<ST_NHWC_POOL, NN>(a, grid, nitems, ntiles, s);
+  }
+}
+
 // Policy.  A workgroup of this form fills its CU's LDS, so launches of two stream lanes can only run side by side on
 // DISJOINT CUs: with L lanes a launch takes at most cap = CUs / L workgroups (kp2d_api.cpp passes L; a profiling forward
 // runs one lane and takes the whole chip).  The form is used when a launch has more than TWO rounds of work items for that
@@ -455,16 +475,21 @@ static bool wsm_eligible(const ConvArgs& a) {
 // as 2 rounds on 96 workgroups, not 1.5 rounds on 128: the first automatic policy lost 5 % at 32 frames and 20 % at
 // 120 x 160 frames that way, profiles/r4_sweep_first_policy.jsonl).  Overrides: ConvArgs::wsm_min / wsm_grid
 // (kp2d_set_option), else KP2D_WSM (0 = never, N = least items) and KP2D_WSM_GRID.
-int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s) {
+// n_item = 64: layers packed in 64-channel groups; 32: the 32-channel layers (npad = 32; automatic use only with KP2D_WSM32=1).
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   static const long min_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : -1;      // -1: automatic
   static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;
+  // 32-channel items are correct (bit-identical, tested through kp2d_set_option) but not faster: conv2a / 2b / 3a 0.088-0.094 ms
+  // against 0.087-0.089 ms on the wide LDS-DMA tiles, -0.8 % end to end (profiles/r4_ab_wsm32.txt) — automatic use is off
+  static const bool n32_on = getenv("KP2D_WSM32") && getenv("KP2D_WSM32")[0] == '1';
   if (a0.wsm_min < 0 || (a0.wsm_min == 0 && min_env == 0)) return -1000;
-  if (!wsm_eligible(a0)) return -1000;
+  if (n_item != 64 && n_item != 32) return -1000;
+  if (!wsm_eligible(a0, n_item)) return -1000;
   ConvArgs a = a0;
   a.tiles_x = (a.W + M_TW - 1) / M_TW;
   a.tiles_y = (a.H + M_TH - 1) / M_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
-  const long nitems = ntiles * (a.npad / M_N);
+  const long nitems = ntiles * (a.npad / n_item);
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int lanes = a.wsm_lanes > 1 ? a.wsm_lanes : 1;
@@ -473,29 +498,19 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s) {
   cap &= ~7;                                                   // a multiple of 8: contiguous runs per XCD
   const bool automatic = a.wsm_min == 0 && min_env < 0;
   // automatic: at least three rounds of work per workgroup (the form's start-up — two steps of loads before the first
-  // product — and its drain are paid per launch: at 32 frames, 192 items per lane, it lost 7 % end to end) and at least
-  // four chunks per item (conv3b, two chunks and two stores per item, is slower in this form: 0.165 against 0.157 ms)
+  // product — and its drain are paid per launch: at 32 frames, 192 items per lane, it lost 7 % end to end) and, for the
+  // 64-channel items, at least four chunks (conv3b, two chunks and two stores per item, is slower in this form: 0.165
+  // against 0.157 ms)
   const long min_items = a.wsm_min > 0 ? a.wsm_min : (min_env > 0 ? min_env : 2 * cap + 1);
   if (cap < 8 || nitems < min_items || nitems >= (1L << 30)) return -1000;
-  if (automatic && a.cin < 64) return -1000;
+  if (automatic && n_item == 64 && a.cin < 64) return -1000;
+  if (automatic && n_item == 32 && !n32_on) return -1000;
   const long rounds = (nitems + cap - 1) / cap;
   int grid = (int)(((nitems + rounds - 1) / rounds + 7) & ~7L);
   if (grid > cap) grid = cap;
   if (grid > nitems) grid = (int)(nitems & ~7L);
   if (grid < 8) return -1000;
-  const void* fn = a.store == ST_NHWC ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC>)
-                 : a.store == ST_SHUFFLE ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_SHUFFLE>)
-                 : a.store == ST_NHWC_BOTH ? reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC_BOTH>)
-                                           : reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<ST_NHWC_POOL>);
-  static PerDeviceOnce lds_once[4];
-  if (int e = lds_opt_in(lds_once[a.store == ST_NHWC ? 0 : a.store == ST_SHUFFLE ? 1 : a.store == ST_NHWC_BOTH ? 2 : 3], fn)) return e;
-  switch (a.store) {
-    case ST_NHWC: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
-    case ST_SHUFFLE: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_SHUFFLE>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
-    case ST_NHWC_BOTH: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC_BOTH>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
-    default: hipLaunchKernelGGL(conv3x3_f16x3_wsm_kernel<ST_NHWC_POOL>, dim3(grid), dim3(M_THREADS), M_LDS, s, a, (int)nitems, (int)ntiles); break;
-  }
-  return (int)hipGetLastError();
+  return n_item == 64 ? wsm_launch<4>(a, grid, nitems, ntiles, s) : wsm_launch<2>(a, grid, nitems, ntiles, s);
 }
 
 }  // namespace kp2d

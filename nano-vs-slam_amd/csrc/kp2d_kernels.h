@@ -72,7 +72,7 @@ int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s); 
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 // conv3x3_wsm.hip: the same layers, 64-channel groups, warp-specialised and persistent; -1000 = not eligible / fewer than min_items work items
-int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s, int n_item);   // n_item: 64 (64-channel groups) or 32 (32-channel layers)
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {
