@@ -228,6 +228,10 @@ int kp2d_set_chunk_frames(kp2d_model* m, int frames);
  *   "ws_min_tiles"   least 16 x 32 pixel tiles of a launch for the warp-specialised form of backbone.conv1b
  *                    (conv3x3_f16x3_ws_kernel); 0 = default (1024).
  *   "wsm_grid"       most workgroups of that form per launch (0 = KP2D_WSM_GRID if set, else CUs / stream lanes).
+ *   "wsm_transposed" that form's tiles walk the map transposed (tile rows = map columns, the taps of the weight pack
+ *                    transposed to match; a different summation order over the nine taps, so results differ from the
+ *                    plain walk in the last bits): 0 = where the matrix-time model says it is cheaper (30 x 40 maps:
+ *                    3 x 1 tiles instead of 2 x 2), 1 = always, -1 = never ("conv3x3_f16x3<wsm>t" in the profile).
  * Unknown keys return KP2D_ERR_ARG.  kp2d_profile_get reports the tile form each conv launch took behind its kernel
  * family ("conv3x3_f16x3<wsm>", "conv3x3_f16x3<2,1,16>", ...). */
 int kp2d_set_option(kp2d_model* m, const char* key, long value);

@@ -29,15 +29,20 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, ablate: bool = False, exp: str = "", defines: tuple = ()) -> str:
     """ablate=True: the timing-ablation build (-DKP2D_ABLATE: KP2D_DBG bits switch phases of the conv kernels off,
-    results are then wrong by design) into build_exp/libkp2d_ablate.so — selected with KP2D_LIB, never the product."""
+    results are then wrong by design) into build_exp/libkp2d_ablate.so — selected with KP2D_LIB, never the product.
+    exp="NAME", defines=("X", ...): an experimental build with -DX ... into build_exp/libkp2d_NAME.so (A/B runs, tools/ab_variants.sh)."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build_exp", "obj_ablate") if ablate else os.path.join(HERE, "build")
+    if exp:
+        objdir = os.path.join(HERE, "build_exp", "obj_" + exp)
     os.makedirs(objdir, exist_ok=True)
     lib = os.path.join(HERE, "build_exp", "libkp2d_ablate.so") if ablate else LIB
-    flags = FLAGS + (["-DKP2D_ABLATE"] if ablate else [])
+    if exp:
+        lib = os.path.join(HERE, "build_exp", "libkp2d_%s.so" % exp)
+    flags = FLAGS + (["-DKP2D_ABLATE"] if ablate else []) + ["-D" + d for d in defines]
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src + ".o")
@@ -60,4 +65,7 @@ def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> st
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))
+    argv = sys.argv[1:]
+    exp = argv[argv.index("--exp") + 1] if "--exp" in argv else ""
+    defs = tuple(argv[i + 1] for i, a in enumerate(argv) if a == "--define")
+    print(build(force="--force" in argv, ablate="--ablate" in argv, exp=exp, defines=defs))

@@ -614,7 +614,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
     // (conv3x3_wsm.hip; policy and overrides at its launcher)
     {
       const int e = launch_conv3x3_f16x3_wsm(a, s, 64);
-      if (e != -1000) { g_variant = "<wsm>"; return e; }
+      if (e != -1000) return e;      // (the launcher noted "<wsm>" or, for the transposed walk, "<wsm>t")
     }
     // map heights that leave the last 16-row tile row at most half full (120 = 7.5 x 16): 8 x 32 tiles, no ragged row
     static const bool flat_on = !(getenv("KP2D_FLAT") && getenv("KP2D_FLAT")[0] == '0');
@@ -634,7 +634,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   // 32-channel layers on grids that fill the chip several times: the warp-specialised persistent form with 32-channel items
   if (a.npad == 32 && !a.ng32) {
     const int e = launch_conv3x3_f16x3_wsm(a, s, 32);
-    if (e != -1000) { g_variant = "<wsm32>"; return e; }
+    if (e != -1000) return e;
   }
   static const bool wide_on = !(getenv("KP2D_WIDE") && getenv("KP2D_WIDE")[0] == '0');
   const long wide_tiles = (long)((a.W + 31) / 32) * a.tiles_y * a.B * (a.npad / 32);

@@ -71,7 +71,15 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool consumer = wave < 8;                    // wave-uniform by construction (see the barrier contract above)
-  const int H = a.H, W = a.W;
+  // Tile space.  A tile is 16 rows x 32 columns of (H, W); with a.wsm_tr those are the map's COLUMNS x ROWS — the tile walks
+  // the map transposed (tile row = map column), the weight slab has its taps transposed to match (kp2d_api.cpp w16t), and
+  // only the two places that form global addresses know: the staging waves' pixel index and the epilogue's (y, x).
+  // Why: a 30 x 40 map is 2 x 2 tiles with 8 of the second tile column's 32 columns inside (24 quarter-SIMD units of matrix
+  // work per frame for 18.75 of pixels); as 40 x 30 it is 3 x 1 tiles, the last with 8 of 16 rows = half of the waves, none
+  // of them multiplying padding (20 units).  The launcher picks the cheaper walk per layer (wsm_walk_cost).
+  const bool tr = a.wsm_tr != 0;
+  const int H = tr ? a.W : a.H, W = tr ? a.H : a.W;
+  const int Wg = a.W;                                // pixels per row of the map in memory
   const int groups = a.npad / M_N;
   const int nchunk = a.cin >> 4;
   const int c0 = a.in0.c;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       for (int it = 0; it < M_IT; ++it) {
         const int gy = y0 + (g_yx[it] >> 8), gx = x0 + (g_yx[it] & 255);
         const bool ok = g_yx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pix[it] = ok ? gy * W + gx : -1;
+        pix[it] = ok ? (tr ? gx * Wg + gy : gy * Wg + gx) : -1;
       }
     };
     auto group_of = [&](int i) { const int j = i * G + off; return groups == 1 ? 0 : j % groups; };
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   constexpr bool full = store != ST_NHWC_POOL;
   constexpr bool pooled = store == ST_NHWC_POOL || store == ST_NHWC_BOTH;
   constexpr int up = store == ST_SHUFFLE ? 2 : 1;
-  const int HH = H * up, WW = W * up, Hp = H >> 1, Wp = W >> 1;
+  const int HH = a.H * up, WW = a.W * up, Hp = a.H >> 1, Wp = a.W >> 1;      // the outputs, as they lie in memory
   const int cq = a.cout >> 2;
   auto finish = [&](const WsmItem& it) {
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -350,8 +358,9 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     int vo[MT], vp[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
-      const int inv = (y < H && x < W) ? 0 : OOB;
+      const int ty = it.y0 + wr * 4 + 2 * (m / CB) + prow, tx = it.x0 + 16 * ph + 8 * (m % CB) + pcol;      // tile space
+      const int inv = (ty < H && tx < W) ? 0 : OOB;
+      const int y = tr ? tx : ty, x = tr ? ty : tx;
       vo[m] = full ? ((up * y * WW + up * x) * a.os0 + 4 * lg) * 4 | inv : 0;
       const int yp = y >> 1, xp = x >> 1;
       const int invp = ((lp & 3) == 0 && yp < Hp && xp < Wp) ? 0 : OOB;      // lane 4 q stores the quad's maximum
@@ -414,13 +423,24 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   int i = 0, ch = 0;
   WsmItem cur = decode(0);
   bool busy = cur.y0 + 4 * wr < H && cur.x0 + 16 * ph < W;      // rows / columns wholly outside the map: nothing to do
+  // The two waves of a SIMD (ph 0 / ph 1) finish an item in the same step.  The first stores it at the END of that step, the
+  // second at the START of the next one — while the first is already multiplying — so the two store bursts do not compete for
+  // the CU's one path to L2 in the same microsecond (+0.3-0.5 % end to end in six of six alternating runs; the other
+  // arrangements tried — priorities, stage hand-over by LDS counters instead of barriers — gained nothing or lost:
+  // profiles/r4_ab_wsm_epilogue_phase.txt).
+  bool due = false;
+  WsmItem prev = cur;
   clear();
   __syncthreads();                                   // barrier 0
   for (int s = 0; s < nsteps_p; ++s) {
     if (s < nsteps) {
+      if (due) { finish(prev); clear(); due = false; }
       if (busy && !KP2D_DBG_ON(8)) multiply((s & 1) * M_STAGE);
       if (++ch == nchunk) {
-        if (busy && !KP2D_DBG_ON(1)) { finish(cur); clear(); }
+        if (busy && !KP2D_DBG_ON(1)) {
+          if (ph == 1) { due = true; prev = cur; }
+          else { finish(cur); clear(); }
+        }
         ch = 0;
         if (++i < n_my) {
           cur = decode(i);
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     }
     __syncthreads();
   }
+  if (due) finish(prev);                             // (the barriers are behind us: no wave waits for this)
 }
 
 // true when the layer can run as the kernel above (launch_conv3x3_f16x3 falls back to the general kernel otherwise)
@@ -447,6 +468,25 @@ static bool wsm_eligible(const ConvArgs& a, int N) {
   const long up = a.store == ST_SHUFFLE ? 4 : 1;
   if ((long)a.H * a.W * up * a.os0 * 4 >= 0x7ffffff0L) return false;
   return true;
+}
+
+// Matrix time of one map walked as Ht x Wt in tile space, in units of one wave's four M-tiles: a multiplying wave (wr, ph)
+// works when its 4 rows x 16 columns touch the map, SIMD s holds waves s and s + 4 = (wr s, ph 0) and (wr (s + 2) & 3, ph 1),
+// and a step lasts as long as its busiest SIMD.  (What the model leaves out — staging, the barrier — is the same per step, and
+// the cheaper walk never has more steps.)
+static int wsm_walk_cost(int Ht, int Wt) {
+  int cost = 0;
+  for (int y0 = 0; y0 < Ht; y0 += M_TH)
+    for (int x0 = 0; x0 < Wt; x0 += M_TW) {
+      int worst = 0;
+      for (int sd = 0; sd < 4; ++sd) {
+        const int b0 = (y0 + 4 * sd < Ht) ? 1 : 0;                                         // ph 0: its 16 columns start at x0
+        const int b1 = (y0 + 4 * ((sd + 2) & 3) < Ht && x0 + 16 < Wt) ? 1 : 0;
+        worst = b0 + b1 > worst ? b0 + b1 : worst;
+      }
+      cost += worst;
+    }
+  return cost;
 }
 
 template <int STORE, int NN>
@@ -486,8 +526,19 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   if (n_item != 64 && n_item != 32) return -1000;
   if (!wsm_eligible(a0, n_item)) return -1000;
   ConvArgs a = a0;
-  a.tiles_x = (a.W + M_TW - 1) / M_TW;
-  a.tiles_y = (a.H + M_TH - 1) / M_TH;
+  // transposed walk (tile rows = map columns) where it is cheaper and the layer has the transposed-tap pack; KP2D_WSM_TR=0 never, =1 always
+  static const int tr_env = getenv("KP2D_WSM_TR") ? atoi(getenv("KP2D_WSM_TR")) : -1;
+  // (ConvArgs::wsm_tr comes in as the caller's wish — kp2d_set_option("wsm_transposed"): 0 automatic, 1 always, -1 never — and
+  // goes to the kernel as the decision)
+  const int tr_mode = a0.wsm_tr != 0 ? a0.wsm_tr : (tr_env < 0 ? 0 : (tr_env > 0 ? 1 : -1));
+  a.wsm_tr = 0;
+  if (n_item == 64 && a.w_tr && tr_mode >= 0 && a.H >= 16 && (tr_mode > 0 || wsm_walk_cost(a.W, a.H) < wsm_walk_cost(a.H, a.W))) {
+    a.wsm_tr = 1;
+    a.w = a.w_tr;
+  }
+  const int Ht = a.wsm_tr ? a.W : a.H, Wt = a.wsm_tr ? a.H : a.W;
+  a.tiles_x = (Wt + M_TW - 1) / M_TW;
+  a.tiles_y = (Ht + M_TH - 1) / M_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   const long nitems = ntiles * (a.npad / n_item);
   int dev = 0, cus = 256;
@@ -510,6 +561,7 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   if (grid > cap) grid = cap;
   if (grid > nitems) grid = (int)(nitems & ~7L);
   if (grid < 8) return -1000;
+  conv3x3_note_variant(n_item == 32 ? "<wsm32>" : (a.wsm_tr ? "<wsm>t" : "<wsm>"));      // (what the engine's profile records)
   return n_item == 64 ? wsm_launch<4>(a, grid, nitems, ntiles, s) : wsm_launch<2>(a, grid, nitems, ntiles, s);
 }
 

@@ -68,6 +68,7 @@ struct ConvPack {
   size_t w_off = 0, sc_off = 0, sh_off = 0;   // float offsets into the blob
   size_t w16_off = 0, sc16_off = 0;           // split-fp16 pack: [hi16|lo16] half rows of w * 2^e, scale * 2^-e (pack())
   size_t w16n_off = 0;                        // the same rows in 32-channel groups (npad >= 64): small-grid launches
+  size_t w16t_off = 0;                        // the 64-channel-group rows with the taps transposed (3x3, npad >= 64): transposed tiles of conv3x3_wsm.hip
   size_t wd_off = 0;                          // head layers (3x3, <= 4 output channels): fp32 [chunk][tap][4][16] for head3x3.hip
   bool head() const { return kind == 0 && cout <= 4 && !shuffle && !tconv && parts.empty(); }
   size_t wd_floats() const { return (size_t)((cin + 15) / 16) * 9 * 4 * 16; }
@@ -144,6 +145,7 @@ struct kp2d_model {
   int chunk_frames = 0;
   int ws_min = 0;         // kp2d_set_option("ws_min_tiles"): least tiles of a launch for the warp-specialised conv1b form (0 = 1024)
   int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
+  int wsm_tr = 0;         // kp2d_set_option("wsm_transposed")
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
@@ -372,6 +374,7 @@ int describe(kp2d_model* m) {
     c.sh_off = take(c.npad);
     c.w16_off = take(c.w16_floats());
     if (c.npad >= 64) c.w16n_off = take(c.w16_floats());
+    if (c.npad >= 64 && c.kind == 0 && c.taps == 9) c.w16t_off = take(c.w16_floats());
     c.sc16_off = take(c.npad);
     if (c.head()) c.wd_off = take(c.wd_floats());
   }
@@ -542,6 +545,13 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
               n16[rown + kk] = hi;
               n16[rown + 16 + kk] = lo;
             }
+            if (c.w16t_off) {     // tap (dy, dx) in the slot of tap (dx, dy): what a tile that walks the map transposed multiplies
+              _Float16* t16 = reinterpret_cast<_Float16*>(&blob[c.w16t_off]);
+              const int slot_t = kSlot[3 * (tap % 3) + tap / 3];
+              const size_t rowt = ((((size_t)grp * nchunk16 + chk) * c.taps + slot_t) * ng + n) * 32;
+              t16[rowt + kk] = hi;
+              t16[rowt + 16 + kk] = lo;
+            }
           }
         }
       }
@@ -648,9 +658,11 @@ struct Plan {
     a.ids_out = (store == ST_NCHW && seg_ids && out0 && out0 == seg_ptr && nsplit == c.cout && c.npad == 32) ? seg_ids : nullptr;
     a.wsm_min = m->wsm_min;
     a.wsm_grid = m->wsm_grid;
+    a.wsm_tr = m->wsm_tr;
     a.ws_min = m->ws_min;
     a.wsm_lanes = nlanes;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
+    a.w_tr = (split && c.w16t_off) ? m->blob + c.w16t_off : nullptr;
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
     // Small grids (a frame or two at a time): a 64-channel-group launch would leave most CUs idle and each of its
     // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
@@ -1553,6 +1565,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "ws_min_tiles") {
     if (value < 0 || value > 0x7fffffffL) return fail(KP2D_ERR_ARG, "ws_min_tiles out of range");
     m->ws_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "wsm_transposed") {      // conv3x3_wsm.hip: tiles walk the map transposed — 0 where cheaper (default), 1 always, -1 never
+    if (value < -1 || value > 1) return fail(KP2D_ERR_ARG, "wsm_transposed is -1, 0 or 1");
+    m->wsm_tr = (int)value;
     return KP2D_OK;
   }
   if (k == "wsm_grid") {

@@ -1030,9 +1030,11 @@ def _kernels_that_ran(model, x):
     return out
 
 
-def _set_wsm(model, value):
+def _set_wsm(model, value, transposed=None):
     eng = model._engine
     assert eng.lib.kp2d_set_option(eng.handle, b"wsm_min_items", value) == 0
+    if transposed is not None:      # -1 never, 0 where the launcher's matrix-time model prefers it, 1 always
+        assert eng.lib.kp2d_set_option(eng.handle, b"wsm_transposed", transposed) == 0
 
 
 @pytest.mark.parametrize("config,v3,ncls,B,H,W", [
@@ -1046,21 +1048,25 @@ def _set_wsm(model, value):
     ("S", False, 28, 1, 240, 320),      # one frame: 40 / 12 / 4 items per launch (n_my = 1 everywhere, tiny grids)
     ("S", False, 28, 9, 64, 96),        # 32 x 48 maps: 2 x 2 tiles with half-empty column blocks, 16 x 24 maps fall back (W < 32)
 ])
-def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3, ncls, B, H, W):
+@pytest.mark.parametrize("walk", ["plain", "transposed"])
+def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3, ncls, B, H, W, walk):
     """Every output of a forward with the multi-chunk 64-channel-group layers on conv3x3_f16x3_wsm_kernel (forced by
     wsm_min_items = 8) against the same forward on the general kernels (wsm_min_items = -1): same arithmetic in the
-    same order, so the results must be bit-identical; and the profile must say the form ran where it was meant to."""
+    same order, so the results must be bit-identical; and the profile must say the form ran where it was meant to.
+    walk = transposed: every such layer with its tiles walking the map transposed (wsm_transposed = 1: tile rows = map
+    columns, transposed-tap weight pack) — the nine taps are then summed in another order, so the comparison is to
+    1e-5 of the output's range instead of to the bit."""
     model, _ = product_model(config, v3, ncls)
     x = torch.from_numpy(synthetic_frames(B, H, W, seed=21)).to(DEV)
     with torch.no_grad():
         model(x[:1])
-        _set_wsm(model, -1)
+        _set_wsm(model, -1, -1)
         ran_off = _kernels_that_ran(model, x)
         ref = {k: v.clone() for k, v in model(x).items()}
-        _set_wsm(model, 8)
+        _set_wsm(model, 8, 1 if walk == "transposed" else -1)
         ran_on = _kernels_that_ran(model, x)
         got = {k: v.clone() for k, v in model(x).items()}
-        _set_wsm(model, 0)
+        _set_wsm(model, 0, 0)
     assert not any("<wsm>" in k for ks in ran_off.values() for k in ks)
     wsm_layers = sorted(l for l, ks in ran_on.items() if any("<wsm>" in k for k in ks))
     # (N: backbone.conv3b is 24 -> 48 channels, not whole 16-channel chunks: it stays on the general kernel)
@@ -1069,6 +1075,13 @@ def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3,
     if config == "S":      # 32 -> 32 layers on 32-channel items of the same kernel
         assert any("<wsm32>" in k for k in ran_on["backbone.conv2a"]) and any("<wsm32>" in k for k in ran_on["backbone.conv3a"]), ran_on["backbone.conv2a"]
     assert ("backbone.conv3b" in wsm_layers or config == "N") and want <= set(wsm_layers), wsm_layers
+    if walk == "transposed":
+        assert all(any("<wsm>t" in k for k in ran_on[l]) for l in wsm_layers), {l: ran_on[l] for l in wsm_layers}
+        for k in ref:
+            r, g = ref[k].float(), got[k].float()
+            assert float((r - g).abs().max()) <= 1e-5 * max(1.0, float(r.abs().max())), (k, float((r - g).abs().max()), float(r.abs().max()))
+        return
+    assert not any("<wsm>t" in k for ks in ran_on.values() for k in ks)
     for k in ref:
         assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()), wsm_layers)
 
@@ -1101,6 +1114,9 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
             # (automatic policy: 30 x 40 maps are one item per workgroup, conv3b has two chunks per item — both stay general)
             if form == "auto" and layer not in ("seg_head.convs.3", "backbone.conv3b"):
                 assert any("<wsm>" in k for k in ran[layer]), (layer, ran[layer])
+                # 60 x 80 and 120 x 160 maps: the plain walk (the transposed one pays on maps like 30 x 40, whose layers —
+                # seg_head.convs.2-4 — are too small for this form at 64 frames)
+                assert not any("<wsm>t" in k for k in ran[layer]), (layer, ran[layer])
             else:
                 assert any("<2,1,16>" in k or "<2,1,8>" in k for k in ran[layer]), (layer, ran[layer])
         assert any("flat32" in k for k in forms), forms
