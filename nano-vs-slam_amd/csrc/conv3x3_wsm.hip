@@ -42,8 +42,8 @@ __host__ __device__ constexpr int m_wl(int n) { return 9 * n * 32; }            
 __host__ __device__ constexpr int m_wslab(int n) { return 2 * m_wl(n); }              // a chunk's weight slab (36,864 B)
 __host__ __device__ constexpr int m_stage(int n) { return M_IMG + m_wslab(n); }       // one stage: image | weights (78,336 B)
 __host__ __device__ constexpr int m_ss(int n) { return 2 * m_stage(n); }              // scale | shift vectors behind the two stages (156,672)
-constexpr int M_MAXN = 256;                            // channels of a layer (scale / shift in LDS)
-__host__ __device__ constexpr int m_lds(int n) { return m_ss(n) + 2 * M_MAXN * 4; }   // 158,720 B / 121,856 B
+constexpr int M_MAXN = 320;                            // channels of a layer (scale / shift in LDS; 320 = the five heads' first layers as one)
+__host__ __device__ constexpr int m_lds(int n) { return m_ss(n) + 2 * M_MAXN * 4; }   // 159,232 B / 122,368 B
 constexpr int M_G = M_ROWS * M_COLS * 4;               // 16-byte granules of a halo image (2448)
 constexpr int M_PT = 256;                              // staging threads
 constexpr int M_IT = (M_G + M_PT - 1) / M_PT;          // granules per staging thread (10)

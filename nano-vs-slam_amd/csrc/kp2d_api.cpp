@@ -898,11 +898,16 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;   // only_encoder(): skip every head but the VPR encoder
   // First CBR of every head in one launch ("heads.first", see describe()); first(name) hands out its channel slices.
   static const bool merge_env = !(getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '0');
-  // Only where a head's own launch would be a small grid (a frame or two per call): there the five launches are five
-  // serial latencies (0.42 -> 0.37 ms per frame); at 32 frames per launch the strided slice reads cost what the
-  // fuller grid gains (20.43k vs 20.36k frames/s).
+  // Where a head's own launch would be a small grid (a frame or two per call) the five launches are five serial latencies
+  // (0.42 -> 0.37 ms per frame).  On big grids the merged layer is ONE launch of the warp-specialised form with five times
+  // the rounds (its start-up and drain paid once: conv family 333 -> 343 TFLOP/s at 64 x 240 x 320) against strided slice
+  // reads in the five consumers: +0.1 ... +0.6 % at 64 frames, +1.4 % at 32, +0.9 % at 16, +0.6 % at 480 x 640, +0.9 % N
+  // (profiles/r4_ab_merged_heads.txt); V3 (three parts), fp32 arithmetic and 30 x 40 head maps measured -0.2 ... -0.8 %
+  // and keep their own launches.  KP2D_MERGE_HEADS: 0 never, 2 always.
   const bool small_grid = (long)((Hc + 15) / 16) * ((Wc + 15) / 16) * P.B < 256;
-  const bool merged = merge_env && small_grid && !only_enc && m->conv_index.count("heads.first");
+  static const bool merge_always = getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '2';
+  const bool big_wsm = m->precision == KP2D_PREC_F16X3 && !v3 && m->wsm_min >= 0 && (long)Hc * Wc >= 60 * 80;
+  const bool merged = merge_env && (small_grid || merge_always || big_wsm) && !only_enc && m->conv_index.count("heads.first");
   Act mx{};
   if (merged) mx = P.cbr("heads.first", xb, nullptr, ST_NHWC);
   auto first = [&](const std::string& name) -> Act {

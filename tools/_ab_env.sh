@@ -1,0 +1,15 @@
+# A/B of an environment switch on one box: tools/_ab_env.sh OUT "VAR=a" "VAR=b" ...
+set -eu -o pipefail
+OUT=$1; shift
+: > "$OUT"
+for round in 1 2 3; do
+  for kv in "$@"; do
+    line=$(env $kv timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 2>/dev/null | tail -1)
+    echo "{\"env\": \"$kv\", \"round\": $round, \"line\": $line}" >> "$OUT"
+    python3 - "$kv" "$line" <<'PY'
+import json, sys
+d = json.loads(sys.argv[2]); r = d.get("roofline", {})
+print(f"{sys.argv[1]:40s} {d['value']:9.1f} {d['unit']}  {d['ms_per_step']:.3f} ms/step  conv {r.get('achieved')} TFLOP/s", flush=True)
+PY
+  done
+done
