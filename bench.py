@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("KP2D_PRECISION", "f16x3"), choices=["f16x3", "fp32"])
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU (pipeline.BatchStream: steps alternate over this many HIP streams, each "
+                         "forward as one engine lane); 1 = one step after the other on one stream, the engine's two lanes inside")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group, one all_gather, rank 0 prints a line marked "
                          "dry_run with no throughput in it (checks the launch path on a box without a GPU)")
@@ -336,24 +339,34 @@ def main():
 
     rank_fps = {}
 
-    def timed(precision):
-        """W untimed + K timed steps in one arithmetic mode; seconds for the K steps, MAX over ranks."""
+    from nano_vs_slam_amd.pipeline import BatchStream
+
+    def timed(precision, in_flight=None, key=None):
+        """W untimed + K timed steps in one arithmetic mode; seconds for the K steps, MAX over ranks.
+        in_flight > 1: the same K steps (same kernels, same batch, every step complete before the closing fence), enqueued
+        alternately on that many streams so that consecutive steps overlap (pipeline.BatchStream)."""
+        in_flight = args.in_flight if in_flight is None else in_flight
+        key = key or precision
         model.set_precision(precision)
+        bs = BatchStream(model, slots=in_flight, top_k=args.top_k, nn_thresh=0.7, device=dev) if in_flight > 1 else None
+        run = (lambda: bs.submit(x)) if bs is not None else step
         with torch.no_grad():
             for _ in range(args.warmup):
-                step()
+                run()
             fence()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                step()
+                run()
             fence()
             dt_ = time.perf_counter() - t0
+        if bs is not None:
+            bs.close()
         t = torch.tensor([dt_], dtype=torch.float64, device=dev)
         if world > 1:
             mine = torch.tensor([B * args.steps / dt_], dtype=torch.float64, device=dev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
-            rank_fps[precision] = [float(v.item()) for v in every]
+            rank_fps[key] = [float(v.item()) for v in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -363,6 +376,8 @@ def main():
     modes = {}
     if not args.no_precision_modes:
         modes[other] = timed(other)
+    # one step after the other on one stream (the engine's own two lanes inside each forward), reported beside the headline
+    dt_serial = timed(args.precision, 1, key="serial") if args.in_flight > 1 else None
     dt = timed(args.precision)
     modes[args.precision] = dt
 
@@ -397,10 +412,15 @@ def main():
         # under KP2D_LANES=1.  So kernel_ms_sum (one lane, nothing overlapped, forward only) may exceed ms_per_step
         # (lanes overlapped, plus post_processing / top-k / gather, which are not in the sum).
         lanes = max(1, min(8, int(os.environ.get("KP2D_LANES", "2"))))
-        roof["lanes"] = min(lanes, B)
+        roof["lanes"] = 1 if args.in_flight > 1 else min(lanes, B)
         roof["kernel_ms_sum"] = round(total_ms / args.profile_steps, 3)
-        roof["timing_note"] = (f"ms_per_step: {roof['lanes']} stream lane(s) overlapped, forward + post_processing + selection; "
-                               "kernel_ms_per_step / kernel_ms_sum / achieved: single-lane HIP events of the forward's launches")
+        if args.in_flight > 1:
+            roof["timing_note"] = (f"ms_per_step = time of the K steps / K with {args.in_flight} steps in flight (alternating HIP streams, one engine "
+                                   "lane each; forward + post_processing + selection); kernel_ms_per_step / kernel_ms_sum / achieved: "
+                                   "single-lane HIP events of the forward's launches, nothing overlapped")
+        else:
+            roof["timing_note"] = (f"ms_per_step: {roof['lanes']} stream lane(s) overlapped, forward + post_processing + selection; "
+                                   "kernel_ms_per_step / kernel_ms_sum / achieved: single-lane HIP events of the forward's launches")
         if split:
             # a bare fp16 MFMA loop sustains 1571 TFLOP/s on this chip (clock drops to ~1.5 GHz under matrix load:
             # tools/probes/mfma_f16_probe.hip, profiles/r1_probe_f16.log) -> 523.7 TFLOP/s of fp32-grade products
@@ -432,7 +452,8 @@ def main():
             "config": {"workload": f"KP2DTiny-{args.config}{'-V3' if args.v3 else ''} {H}x{W}, batch {B}/GPU"
                                    f"{' (rank 0 shard of ' + str(global_batch) + ')' if args.global_batch > 0 else ''}, "
                                    f"all heads (score/loc/desc/seg/NetVLAD) + post_processing + top-{args.top_k} selection",
-                       "global_batch": global_batch, "frame_shards": world, "n_classes": args.n_classes},
+                       "global_batch": global_batch, "frame_shards": world, "n_classes": args.n_classes,
+                       "steps_in_flight": args.in_flight},
             "roofline": roof,
             "precision_modes": {k: {"value": round(frames / v, 1), "unit": "frames/s",
                                     "ms_per_step": round(v / args.steps * 1e3, 3),
@@ -440,6 +461,10 @@ def main():
                                                    if k == "f16x3" else "exact fp32 on v_mfma_f32_32x32x2_f32")}
                                 for k, v in sorted(modes.items())},
         }
+        if dt_serial is not None:
+            line["one_step_at_a_time"] = {"value": round(frames / dt_serial, 1), "unit": "frames/s",
+                                          "ms_per_step": round(dt_serial / args.steps * 1e3, 3),
+                                          "note": "same K steps on ONE stream, each complete before the next starts (two engine lanes inside a forward)"}
         if collective is not None:
             line["collective"] = collective
             line["launcher"] = "self (bench.py started its own ranks)" if os.environ.get("KP2D_BENCH_SELF_LAUNCHED") else "external (torchrun or equivalent)"

@@ -228,10 +228,18 @@ int kp2d_set_chunk_frames(kp2d_model* m, int frames);
  *   "ws_min_tiles"   least 16 x 32 pixel tiles of a launch for the warp-specialised form of backbone.conv1b
  *                    (conv3x3_f16x3_ws_kernel); 0 = default (1024).
  *   "wsm_grid"       most workgroups of that form per launch (0 = KP2D_WSM_GRID if set, else CUs / stream lanes).
+ *   "lanes"          stream lanes one forward splits its batch over (sub-batches run side by side on internal streams;
+ *                    a workspace sized before the change stays valid only for lane counts <= the one it was sized
+ *                    for): 0 = default (KP2D_LANES if set, else 2).  A caller that keeps two batches in flight on two
+ *                    streams of its own (pipeline.BatchStream: each with its own workspace) sets 1 — the two
+ *                    forwards then fill each other's launch tails, which two lanes of ONE forward (same layer at the
+ *                    same time) cannot: 22.9k -> 23.4k frames/s at 64 x 240 x 320.
  *   "wsm_transposed" that form's tiles walk the map transposed (tile rows = map columns, the taps of the weight pack
- *                    transposed to match; a different summation order over the nine taps, so results differ from the
- *                    plain walk in the last bits): 0 = where the matrix-time model says it is cheaper (30 x 40 maps:
- *                    3 x 1 tiles instead of 2 x 2), 1 = always, -1 = never ("conv3x3_f16x3<wsm>t" in the profile).
+ *                    transposed to match): 0 = never (default), 1 = always, 2 = where the matrix-time model says it is
+ *                    cheaper (30 x 40 maps: 3 x 1 tiles instead of 2 x 2).  It sums the nine taps in another order, so
+ *                    results differ from every other tile form in the last bits — which is why it is opt-in: with it
+ *                    off, outputs are bit-identical whatever the batch size, lane count or tile form
+ *                    ("conv3x3_f16x3<wsm>t" in the profile).
  * Unknown keys return KP2D_ERR_ARG.  kp2d_profile_get reports the tile form each conv launch took behind its kernel
  * family ("conv3x3_f16x3<wsm>", "conv3x3_f16x3<2,1,16>", ...). */
 int kp2d_set_option(kp2d_model* m, const char* key, long value);

@@ -526,13 +526,14 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   if (n_item != 64 && n_item != 32) return -1000;
   if (!wsm_eligible(a0, n_item)) return -1000;
   ConvArgs a = a0;
-  // transposed walk (tile rows = map columns) where it is cheaper and the layer has the transposed-tap pack; KP2D_WSM_TR=0 never, =1 always
-  static const int tr_env = getenv("KP2D_WSM_TR") ? atoi(getenv("KP2D_WSM_TR")) : -1;
-  // (ConvArgs::wsm_tr comes in as the caller's wish — kp2d_set_option("wsm_transposed"): 0 automatic, 1 always, -1 never — and
-  // goes to the kernel as the decision)
-  const int tr_mode = a0.wsm_tr != 0 ? a0.wsm_tr : (tr_env < 0 ? 0 : (tr_env > 0 ? 1 : -1));
+  // Transposed walk (tile rows = map columns; needs the layer's transposed-tap pack).  OFF unless asked for: it sums the nine
+  // taps in another order than every other form, and the engine's results are bit-identical whatever the batch size, lane
+  // count or tile form — a walk chosen by grid size would break that.  ConvArgs::wsm_tr in (kp2d_set_option
+  // "wsm_transposed", else KP2D_WSM_TR): 0 never, 1 always, 2 where the matrix-time model says it is cheaper; out: the decision.
+  static const int tr_env = getenv("KP2D_WSM_TR") ? atoi(getenv("KP2D_WSM_TR")) : 0;
+  const int tr_mode = a0.wsm_tr != 0 ? a0.wsm_tr : tr_env;
   a.wsm_tr = 0;
-  if (n_item == 64 && a.w_tr && tr_mode >= 0 && a.H >= 16 && (tr_mode > 0 || wsm_walk_cost(a.W, a.H) < wsm_walk_cost(a.H, a.W))) {
+  if (n_item == 64 && a.w_tr && tr_mode > 0 && a.H >= 16 && (tr_mode == 1 || wsm_walk_cost(a.W, a.H) < wsm_walk_cost(a.H, a.W))) {
     a.wsm_tr = 1;
     a.w = a.w_tr;
   }

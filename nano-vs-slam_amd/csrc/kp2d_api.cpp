@@ -150,6 +150,7 @@ struct kp2d_model {
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
   int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
+  int lanes_default = 2;  // what kp2d_set_option("lanes", 0) restores
   std::vector<hipStream_t> lane_streams;
   std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
@@ -1162,6 +1163,7 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   if (rc != KP2D_OK) { delete m; return rc; }
   const char* nlanes = getenv("KP2D_LANES");
   if (nlanes) m->lanes = std::max(1, std::min(8, atoi(nlanes)));
+  m->lanes_default = m->lanes;
   *out = m;
   return KP2D_OK;
 }
@@ -1572,8 +1574,13 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
     m->ws_min = (int)value;
     return KP2D_OK;
   }
-  if (k == "wsm_transposed") {      // conv3x3_wsm.hip: tiles walk the map transposed — 0 where cheaper (default), 1 always, -1 never
-    if (value < -1 || value > 1) return fail(KP2D_ERR_ARG, "wsm_transposed is -1, 0 or 1");
+  if (k == "lanes") {      // stream lanes of one forward: 0 = the default (KP2D_LANES, else 2); 1 when the CALLER keeps several batches in flight
+    if (value < 0 || value > 8) return fail(KP2D_ERR_ARG, "lanes is 0 (default) .. 8");
+    m->lanes = value == 0 ? m->lanes_default : (int)value;
+    return KP2D_OK;
+  }
+  if (k == "wsm_transposed") {      // conv3x3_wsm.hip: tiles walk the map transposed — 0 never (default), 1 always, 2 where cheaper
+    if (value < 0 || value > 2) return fail(KP2D_ERR_ARG, "wsm_transposed is 0, 1 or 2");
     m->wsm_tr = (int)value;
     return KP2D_OK;
   }

@@ -47,7 +47,7 @@ struct ConvArgs {
   int ng32;                           // 1: w holds 32-channel groups although npad >= 64 (small grids)
   int wsm_min;                        // least (tile, group) work items for the warp-specialised multi-chunk form; 0: automatic (KP2D_WSM, else one per workgroup); < 0: never
   const float* w_tr;                  // the 64-channel-group pack with the taps transposed (dy <-> dx), nullptr: none (conv3x3_wsm.hip: transposed tiles)
-  int wsm_tr;                         // conv3x3_wsm.hip: tiles walk the map transposed (tile rows = map columns).  In: 0 automatic, 1 always, -1 never; the launcher hands the kernel its decision (0 / 1)
+  int wsm_tr;                         // conv3x3_wsm.hip: tiles walk the map transposed (tile rows = map columns).  In: 0 never, 1 always, 2 where cheaper; the launcher hands the kernel its decision (0 / 1)
   int wsm_lanes;                      // stream lanes launching side by side (the form takes CUs / lanes workgroups)
   long long* ids_out;                 // ST_NCHW, one channel group: also write argmax over the stored channels per pixel, [B][H][W] int64 (nullptr: no)
   int ws_min;                         // least tiles for the warp-specialised conv1b form (0: 1024)

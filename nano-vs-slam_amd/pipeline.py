@@ -366,6 +366,88 @@ class FrameStream:
             yield self.result()
 
 
+class BatchStream:
+    """Whole batches through the network with ``slots`` batches in flight (throughput path; the batched counterpart of
+    ``FrameStream``).  The reference evaluates batches one after the other (``model(x)`` in a loop,
+    src/kp2dtiny/evaluation.py:95-140, src/train_tiny.py validation); on one stream every layer of batch n + 1 waits for
+    the last workgroup of batch n's last kernel, and inside a batch every launch has a tail in which most of the chip
+    idles.  Here consecutive batches alternate over ``slots`` HIP streams, each with its own engine workspace, and the
+    engine runs each forward as ONE stream lane (``kp2d_set_option("lanes", 1)``): the two batches in flight are at
+    different layers at any moment, so one's launch tails and its small post-processing kernels lie under the other's
+    big launches.  Two stream lanes INSIDE one forward (the engine's default) run the same layer at the same time and
+    cannot do that: 64 x 240 x 320: 22.9k frames/s one batch at a time, 23.4k with two in flight (same box; three or
+    four in flight: no further gain).  Results are those of ``net(x)`` + ``post_processing`` + ``select_and_gather``
+    on one stream, bit for bit (same kernels; the lane count changes no arithmetic —
+    tests/test_gpu_parity.py::test_batch_stream_equals_the_plain_loop).
+
+        bs = BatchStream(net, top_k=1000)
+        for out, pts, desc, cnt in bs.map(batches): ...     # or h = bs.submit(x) ... bs.result(h)
+
+    ``submit`` orders the slot's work behind everything already queued on the caller's current stream (so ``x`` may
+    come from it); ``result`` makes the caller's current stream wait for the slot (no host synchronisation) and
+    returns the step's tensors, which stay valid until the slot is submitted again ``slots`` batches later.
+    """
+
+    def __init__(self, net, slots=2, top_k=1000, nn_thresh=0.7, device="cuda", select=True):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("BatchStream needs a HIP device (there is no CPU path)")
+        self.dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.net, self.slots, self.top_k, self.thr, self.select = net, max(1, int(slots)), top_k, nn_thresh, select
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.slots)]
+        self.events = [torch.cuda.Event() for _ in range(self.slots)]
+        self._ws = [None] * self.slots
+        self._res = [None] * self.slots
+        self._n = 0
+        self._eng = net._get_engine(self.dev)
+        if self.slots > 1:       # several forwards side by side: each as one lane (see the class comment)
+            _lib.check(self._eng.lib.kp2d_set_option(self._eng.handle, b"lanes", 1))
+
+    def close(self):
+        """Back to the engine's default lane count (for callers that go on with plain ``net(x)``)."""
+        torch.cuda.synchronize(self.dev)
+        if self.slots > 1:
+            _lib.check(self._eng.lib.kp2d_set_option(self._eng.handle, b"lanes", 0))
+        self._eng._ws = None
+
+    def submit(self, x: torch.Tensor) -> int:
+        from .selectors import _cap, select_and_gather
+        slot = self._n % self.slots
+        self._n += 1
+        st = self.streams[slot]
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        B, _, H, W = x.shape
+        need = int(self._eng.lib.kp2d_workspace_bytes(self._eng.handle, B, H, W))
+        if self._ws[slot] is None or self._ws[slot].numel() < need:
+            self._ws[slot] = torch.empty(max(need, 256), dtype=torch.uint8, device=self.dev)
+        with torch.cuda.stream(st), torch.no_grad():
+            x.record_stream(st)
+            self._eng._ws = self._ws[slot]          # the forward takes the engine's cached workspace: this slot's own
+            out = self.net.post_processing(self.net(x), H, W)
+            if self.select:
+                _idx, _val, cnt, pts, desc = select_and_gather(out["score"], out["coord"], out["feat"],
+                                                               _cap(self.top_k, out["score"]), self.thr)
+                self._res[slot] = (out, pts, desc, cnt)
+            else:
+                self._res[slot] = (out, None, None, None)
+            self.events[slot].record(st)
+        return slot
+
+    def result(self, slot: int):
+        torch.cuda.current_stream(self.dev).wait_event(self.events[slot])
+        return self._res[slot]
+
+    def map(self, batches):
+        """Yield every batch's (out, pts, desc, cnt) in order, ``slots - 1`` batches behind the submissions."""
+        pending = []
+        for x in batches:
+            pending.append(self.submit(x))
+            if len(pending) == self.slots:
+                yield self.result(pending.pop(0))
+        while pending:
+            yield self.result(pending.pop(0))
+
+
 @torch.no_grad()
 def two_view_match(net, matcher, image0: torch.Tensor, image1: torch.Tensor, max_num_keypoints: int = 1024):
     """Extractor + LightGlue on batches of image pairs, everything on the device — the model-facing sequence of

@@ -1033,7 +1033,7 @@ def _kernels_that_ran(model, x):
 def _set_wsm(model, value, transposed=None):
     eng = model._engine
     assert eng.lib.kp2d_set_option(eng.handle, b"wsm_min_items", value) == 0
-    if transposed is not None:      # -1 never, 0 where the launcher's matrix-time model prefers it, 1 always
+    if transposed is not None:      # 0 never (default), 1 always, 2 where the launcher's matrix-time model prefers it
         assert eng.lib.kp2d_set_option(eng.handle, b"wsm_transposed", transposed) == 0
 
 
@@ -1060,10 +1060,10 @@ def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3,
     x = torch.from_numpy(synthetic_frames(B, H, W, seed=21)).to(DEV)
     with torch.no_grad():
         model(x[:1])
-        _set_wsm(model, -1, -1)
+        _set_wsm(model, -1, 0)
         ran_off = _kernels_that_ran(model, x)
         ref = {k: v.clone() for k, v in model(x).items()}
-        _set_wsm(model, 8, 1 if walk == "transposed" else -1)
+        _set_wsm(model, 8, 1 if walk == "transposed" else 0)
         ran_on = _kernels_that_ran(model, x)
         got = {k: v.clone() for k, v in model(x).items()}
         _set_wsm(model, 0, 0)
@@ -1114,9 +1114,7 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
             # (automatic policy: 30 x 40 maps are one item per workgroup, conv3b has two chunks per item — both stay general)
             if form == "auto" and layer not in ("seg_head.convs.3", "backbone.conv3b"):
                 assert any("<wsm>" in k for k in ran[layer]), (layer, ran[layer])
-                # 60 x 80 and 120 x 160 maps: the plain walk (the transposed one pays on maps like 30 x 40, whose layers —
-                # seg_head.convs.2-4 — are too small for this form at 64 frames)
-                assert not any("<wsm>t" in k for k in ran[layer]), (layer, ran[layer])
+                assert not any("<wsm>t" in k for k in ran[layer]), (layer, ran[layer])      # (the transposed walk is opt-in)
             else:
                 assert any("<2,1,16>" in k or "<2,1,8>" in k for k in ran[layer]), (layer, ran[layer])
         assert any("flat32" in k for k in forms), forms
@@ -1290,6 +1288,41 @@ def test_descriptor_matching_mutual_and_compaction():
     dmat = np.sqrt(((d0[0][:, None] - d1[0][None]) ** 2).sum(-1, dtype=np.float32))
     assert q == list(range(k0)) and np.array_equal(tr, np.argmin(dmat, 1))
     assert bf_match_nn(d0[0][:0], d1[0]) == ([], [], [])
+
+
+@pytest.mark.parametrize("slots", [2, 3])
+def test_batch_stream_equals_the_plain_loop(slots):
+    """pipeline.BatchStream (several batches in flight on alternating HIP streams, one engine lane per forward, a
+    workspace per slot) against net(x) + post_processing + select_and_gather one batch after the other on one stream
+    with the engine's default two lanes: the same kernels on the same data, so every tensor must agree bit for bit —
+    including after the slots have been reused (5 batches over 2 / 3 slots) and for a ragged last batch."""
+    from nano_vs_slam_amd.pipeline import BatchStream
+    from nano_vs_slam_amd.selectors import select_and_gather
+    model, _ = product_model("S", False, 28)
+    H, W = 96, 128
+    batches = [torch.from_numpy(synthetic_frames(b, H, W, seed=40 + i)).to(DEV) for i, b in enumerate((6, 6, 6, 6, 3))]
+    want = []
+    with torch.no_grad():
+        for x in batches:
+            out = model.post_processing(model(x), H, W)
+            _i, _v, cnt, pts, desc = select_and_gather(out["score"], out["coord"], out["feat"], 300, 0.7)
+            want.append(({k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, pts.clone(), desc.clone(), cnt.clone()))
+    bs = BatchStream(model, slots=slots, top_k=300, nn_thresh=0.7, device=DEV)
+    got = []
+    for out, pts, desc, cnt in bs.map(batches):
+        got.append(({k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, pts.clone(), desc.clone(), cnt.clone()))
+    bs.close()
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for (wo, wp, wd, wc), (go, gp, gd, gc) in zip(want, got):
+        assert set(wo) == set(go)
+        for k in wo:
+            assert torch.equal(wo[k], go[k]), k
+        assert torch.equal(wc, gc) and torch.equal(wp, gp) and torch.equal(wd, gd)
+    # the engine is back on its default lane count: a plain forward afterwards still agrees
+    with torch.no_grad():
+        again = model.post_processing(model(batches[0]), H, W)
+    assert torch.equal(again["score"], want[0][0]["score"])
 
 
 @pytest.mark.parametrize("semantic", [False, True])

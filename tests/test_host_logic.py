@@ -82,6 +82,13 @@ def test_no_cpu_path():
         m.backbone(torch.zeros(1, 3, 32, 32))      # parameter holders never execute torch ops
 
 
+def test_batch_stream_has_no_cpu_path():
+    """pipeline.BatchStream (batches in flight on HIP streams) refuses a CPU device instead of running anything there."""
+    from nano_vs_slam_amd.pipeline import BatchStream
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        BatchStream(object(), slots=2, device="cpu")
+
+
 def test_unbuilt_variants_raise_not_fallback():
     with pytest.raises(NotImplementedError):       # heads.py:58 / segmentation.py:120
         K.KP2DTinyV2(**K.get_config("S"), nClasses=28, upscale_method="bilinear")

@@ -39,10 +39,10 @@ timeout -k 10 200 python3 tools/bench_frontend.py 2>"$(errf)" | tail -1 > "$OUT/
 timeout -k 10 200 python3 tools/bench_frontend.py --pinned 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 cut -c1-200 "$OUT/frontend.jsonl"
-step "rocprofv3 kernel stats, default two lanes"
+step "rocprofv3 kernel stats, the default bench command (two steps in flight: kernels of the two streams overlap, durations are wall time under sharing)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats2.log" 2>&1
-step "rocprofv3 kernel stats, single lane"
-KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats1.log" 2>&1
+step "rocprofv3 kernel stats, one step at a time on a single lane (nothing overlaps: the launch shape of bench.py's HIP-event figures)"
+KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes --in-flight 1 > "$OUT/stats1.log" 2>&1
 find "$OUT/stats1" "$OUT/stats2" -name "*kernel_trace.csv" -delete      # only the --stats summaries are kept
 
 step "per-layer table"
