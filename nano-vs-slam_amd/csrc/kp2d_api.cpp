@@ -1549,6 +1549,7 @@ int kp2d_profile_get(kp2d_model* m, int index, const char** layer, const char** 
 int kp2d_set_precision(kp2d_model* m, int mode) {
   if (!m || (mode != KP2D_PREC_FP32 && mode != KP2D_PREC_F16X3)) return fail(KP2D_ERR_ARG, "precision must be KP2D_PREC_FP32 or KP2D_PREC_F16X3");
   m->precision = mode;
+  m->plan_cache.clear();      // (which layers run merged depends on the arithmetic mode: plan sizes are memoised per mode)
   return KP2D_OK;
 }
 
@@ -1564,6 +1565,7 @@ int kp2d_set_tap(kp2d_model* m, const char* layer, float* dst, size_t capacity_f
 int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (!m || !key) return fail(KP2D_ERR_ARG, "bad argument");
   const std::string k = key;
+  m->plan_cache.clear();      // (an option may change the plan: sizes are memoised per setting)
   if (k == "wsm_min_items") {
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "wsm_min_items out of range");
     m->wsm_min = (int)value;

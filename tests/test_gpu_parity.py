@@ -1290,6 +1290,25 @@ def test_descriptor_matching_mutual_and_compaction():
     assert bf_match_nn(d0[0][:0], d1[0]) == ([], [], [])
 
 
+def test_plan_sizes_follow_the_arithmetic_mode_and_options():
+    """The engine memoises a plan's workspace size per (frames, H, W).  Which layers run merged (the five heads' first
+    layers as one 320-channel launch) depends on the arithmetic mode and on options, so the memo must not outlive a
+    kp2d_set_precision / kp2d_set_option: fp32 first, then f16x3 at the same shape used to fail with 'workspace exhausted'."""
+    model, _ = product_model("S", False, 28)
+    x = torch.from_numpy(synthetic_frames(4, 240, 320, seed=3)).to(DEV)
+    eng = model._get_engine(torch.device(DEV))
+    with torch.no_grad():
+        model.set_precision("fp32")
+        a = model(x)["score"].clone()
+        model.set_precision("f16x3")
+        for lanes in (1, 2, 0):
+            assert eng.lib.kp2d_set_option(eng.handle, b"lanes", lanes) == 0
+            eng._ws = None
+            b = model(x)["score"].clone()
+            assert float((a - b).abs().max()) < TOL
+        assert eng.lib.kp2d_set_option(eng.handle, b"lanes", 9) != 0
+
+
 @pytest.mark.parametrize("slots", [2, 3])
 def test_batch_stream_equals_the_plain_loop(slots):
     """pipeline.BatchStream (several batches in flight on alternating HIP streams, one engine lane per forward, a

@@ -28,7 +28,7 @@ sweep --height 480 --width 640 --batch 32
 sweep --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32
 sweep --config S_A --v3
 sweep --config N
-sweep --batch 1 --steps 300
+sweep --batch 1 --steps 300 --in-flight 1      # (a latency figure: one frame at a time)
 sweep --precision fp32
 step "LightGlue"
 timeout -k 10 200 python3 tools/bench_lightglue.py --steps 100 --warmup 10 2>"$(errf)" | tail -1 > "$OUT/lightglue.jsonl"
