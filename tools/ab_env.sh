@@ -1,10 +1,12 @@
-# A/B of an environment switch on one box: tools/_ab_env.sh OUT "VAR=a" "VAR=b" ...
+#!/bin/bash
+# A/B of an environment switch on one GPU box (boxes differ by +-3 %: only runs of one session compare):
+#   tools/ab_env.sh OUT.jsonl "VAR=a" "VAR=b" ...      three alternating rounds of the bench.py line; stderr -> OUT.err
 set -eu -o pipefail
 OUT=$1; shift
 : > "$OUT"
 for round in 1 2 3; do
   for kv in "$@"; do
-    line=$(env $kv timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 2>/dev/null | tail -1)
+    line=$(env $kv timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-precision-modes --steps 40 2>>"${OUT%.jsonl}.err" | tail -1)
     echo "{\"env\": \"$kv\", \"round\": $round, \"line\": $line}" >> "$OUT"
     python3 - "$kv" "$line" <<'PY'
 import json, sys

@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Batches in flight: throughput of forward + post_processing + selection at 64 x 240 x 320 with 1, 2, 3, ... independent
+(model replica, HIP stream) slots fed alternately — the experiment behind pipeline.BatchStream (which shares ONE engine
+handle and gives each slot its own workspace instead of a replica).
+
+    SLOTS=1,2,3,4 KP2D_LANES=1 python3 tools/bench_in_flight.py       # one engine lane per forward
+    SLOTS=1,2 python3 tools/bench_in_flight.py                        # the engine's default two lanes per forward
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
