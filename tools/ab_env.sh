@@ -11,7 +11,8 @@ for round in 1 2 3; do
     python3 - "$kv" "$line" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2]); r = d.get("roofline", {})
-print(f"{sys.argv[1]:40s} {d['value']:9.1f} {d['unit']}  {d['ms_per_step']:.3f} ms/step  conv {r.get('achieved')} TFLOP/s", flush=True)
+one = d.get("one_step_at_a_time", {}).get("value")
+print(f"{sys.argv[1]:40s} {d['value']:9.1f} {d['unit']}  {d['ms_per_step']:.3f} ms/step  (one step at a time: {one})  conv {r.get('achieved')} TFLOP/s", flush=True)
 PY
   done
 done
