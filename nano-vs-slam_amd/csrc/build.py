@@ -20,6 +20,11 @@ HEADERS = ["kp2d_kernels.h", "device_guard.h", "device_logic.h", "conv_common.h"
 LIB = os.path.join(HERE, "libkp2d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file additions.  attention.hip: without -fno-honor-nans every fmaxf of the running-maximum chain is preceded by
+# v_max_f32 x, x (quieting a signalling NaN): 4 of ~60 vector instructions per 32 x 32 tile of a kernel bound by vector
+# issue.  (Only NaNs are assumed away; the -inf masks of ragged key tiles are ordinary values.)
+_NN = ["-fno-honor-nans"]
+FILE_FLAGS = {} if os.environ.get("KP2D_NO_FILE_FLAGS") else {f: _NN for f in os.environ.get("KP2D_NN_FILES", "attention.hip").split(",")}      # (the switches: A/B builds)
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -48,7 +53,7 @@ def build(force: bool = False, verbose: bool = True, ablate: bool = False, exp: 
         obj = os.path.join(objdir, src + ".o")
         path = os.path.join(HERE, src)
         if force or _stale(obj, [path] + hdrs):
-            cmd = [HIPCC] + flags + ["-c", path, "-o", obj]
+            cmd = [HIPCC] + flags + FILE_FLAGS.get(src, []) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=HERE)
