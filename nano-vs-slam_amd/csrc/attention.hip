@@ -397,8 +397,9 @@ __device__ __forceinline__ void att_tile(const _Float16* krow, const _Float16* v
     mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   }
   // first tile: the reference becomes the tile maximum whatever its sign (m and o start at 0); later it only rises
-  const float delta = st.first ? mx : fmaxf(mx, 0.f);
-  if (__any(delta != 0.f)) {                // some query of this wave moves its reference: shift and rescale
+  // (the common tile — no key beats any query's reference — pays one compare: delta itself is formed inside the branch)
+  if (st.first || __any(mx > 0.f)) {        // some query of this wave moves its reference: shift and rescale
+    const float delta = st.first ? mx : fmaxf(mx, 0.f);
     st.m += delta;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sc[r] -= delta; st.negm[r] = -st.m; }
