@@ -398,6 +398,7 @@ class BatchStream:
         self.events = [torch.cuda.Event() for _ in range(self.slots)]
         self._ws = [None] * self.slots
         self._res = [None] * self.slots
+        self._pin_out, self._held = {}, {}
         self._n = 0
         self._eng = net._get_engine(self.dev)
         if self.slots > 1:       # several forwards side by side: each as one lane (see the class comment)
@@ -436,6 +437,78 @@ class BatchStream:
     def result(self, slot: int):
         torch.cuda.current_stream(self.dev).wait_event(self.events[slot])
         return self._res[slot]
+
+    # ---- the same with the frames in HOST memory (the PCIe-inclusive path of ``inference()`` for whole batches) ----
+    def submit_frames(self, frames, new_size=None) -> int:
+        """uint8 frames [B,Hs,Ws,3] in host memory (numpy or torch) -> a slot.  The slot's stream reads them across
+        PCIe — pinned, contiguous frames in place with the preprocess kernel (device-visible memory: one pass over the
+        bus at the kernel's own rate, no copy engine; the buffer must stay untouched until ``result_host``), pageable
+        ones by torch's staged copy and then straight into the first layer, as ``inference()`` does — then runs forward,
+        post_processing and selection, and copies the selected rows (counts, points, descriptors) into the slot's
+        pinned output buffers, all behind the other slots' compute.  ``result_host(slot)`` waits for that one slot."""
+        from .selectors import _cap, select_and_gather
+        t = _as_frames(frames)
+        if t.device.type != "cpu":
+            raise ValueError("submit_frames takes host frames (device tensors: forward_frames / submit)")
+        slot = self._n % self.slots
+        self._n += 1
+        st = self.streams[slot]
+        B, Hs, Ws, _ = t.shape
+        H, W = (Hs, Ws) if new_size is None else (int(new_size[0]), int(new_size[1]))
+        zero_copy = _pinned_zero_copy(t)
+        self._held[slot] = t if zero_copy else None
+        need = int(self._eng.lib.kp2d_workspace_bytes(self._eng.handle, B, H, W))
+        if self._ws[slot] is None or self._ws[slot].numel() < need:
+            self._ws[slot] = torch.empty(max(need, 256), dtype=torch.uint8, device=self.dev)
+        with torch.cuda.stream(st), torch.no_grad():
+            self._eng._ws = self._ws[slot]
+            if zero_copy or not _fused_front(self.net):
+                if not zero_copy:
+                    t = t.to(self.dev, non_blocking=True)
+                x = torch.empty(B, 3, H, W, device=self.dev)
+                _lib.check(_lib.load().kp2d_preprocess(C.c_void_p(t.data_ptr()), B, Hs, Ws, C.c_void_p(x.data_ptr()), H, W,
+                                                       C.c_void_p(st.cuda_stream)))
+                fwd = self.net(x)
+            else:
+                # pageable frames: torch's staged upload on this slot's stream, then straight into the first layer
+                # (kp2d_forward_frames) — what inference() does, with the other slots' kernels running meanwhile
+                fwd = self.net.forward_frames(t.to(self.dev, non_blocking=True), (H, W))
+            out = self.net.post_processing(fwd, H, W)
+            _idx, _val, cnt, pts, desc = select_and_gather(out["score"], out["coord"], out["feat"],
+                                                           _cap(self.top_k, out["score"]), self.thr)
+            if new_size is not None and (H, W) != (Hs, Ws):     # pts / scale: visual_odometry.py:81-83, 119-121
+                pts = pts / torch.tensor([W / float(Ws), H / float(Hs)], device=pts.device, dtype=pts.dtype)
+            ho = self._pin_out.get(slot)
+            if ho is None or ho[1].shape != pts.shape or ho[2].shape != desc.shape:
+                ho = self._pin_out[slot] = (torch.empty(cnt.shape, dtype=cnt.dtype).pin_memory(),
+                                            torch.empty(pts.shape, dtype=pts.dtype).pin_memory(),
+                                            torch.empty(desc.shape, dtype=desc.dtype).pin_memory())
+            ho[0].copy_(cnt, non_blocking=True)
+            ho[1].copy_(pts, non_blocking=True)
+            ho[2].copy_(desc, non_blocking=True)
+            self._res[slot] = (out, pts, desc, cnt)
+            self.events[slot].record(st)
+        return slot
+
+    def result_host(self, slot: int):
+        """(pts, feat, out) of a ``submit_frames`` slot as ``inference()`` returns them for a batch: per-frame numpy
+        arrays [n,2] / [n,C] (views of the slot's pinned buffers: valid until the slot is submitted again) and the
+        post-processed dict (device tensors)."""
+        self.events[slot].synchronize()
+        hc, hp, hd = self._pin_out[slot]
+        counts = hc.tolist()
+        hp, hd = hp.numpy(), hd.numpy()
+        self._held[slot] = None
+        return [hp[b, :n] for b, n in enumerate(counts)], [hd[b, :n] for b, n in enumerate(counts)], self._res[slot][0]
+
+    def map_frames(self, batches, new_size=None):
+        pending = []
+        for f in batches:
+            pending.append(self.submit_frames(f, new_size))
+            if len(pending) == self.slots:
+                yield self.result_host(pending.pop(0))
+        while pending:
+            yield self.result_host(pending.pop(0))
 
     def map(self, batches):
         """Yield every batch's (out, pts, desc, cnt) in order, ``slots - 1`` batches behind the submissions."""

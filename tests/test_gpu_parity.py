@@ -1290,6 +1290,31 @@ def test_descriptor_matching_mutual_and_compaction():
     assert bf_match_nn(d0[0][:0], d1[0]) == ([], [], [])
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_batch_stream_host_frames_equal_inference(pinned):
+    """BatchStream.submit_frames / result_host (uint8 frames in host memory, two batches in flight, the preprocess kernel
+    reading pinned memory across PCIe, selected rows copied back behind the next batch's kernels) against
+    pipeline.inference() batch by batch: same points and descriptors, frame by frame, including a resize."""
+    from nano_vs_slam_amd.pipeline import BatchStream, inference
+    model, _ = product_model("S", False, 28)
+    rng = np.random.default_rng(5)
+    batches = [rng.integers(0, 256, (b, 120, 160, 3), dtype=np.uint8) for b in (4, 4, 4, 2)]
+    srcs = [torch.from_numpy(f).pin_memory() if pinned else f for f in batches]
+    for new_size in (None, (96, 128)):
+        want = [inference(model, f, new_size, 0.7, 300, DEV) for f in batches]
+        want = [([p.copy() for p in w[0]], [d.copy() for d in w[1]]) for w in want]
+        bs = BatchStream(model, slots=2, top_k=300, nn_thresh=0.7, device=DEV)
+        got = [([p.copy() for p in r[0]], [d.copy() for d in r[1]]) for r in bs.map_frames(srcs, new_size)]
+        bs.close()
+        assert len(got) == len(want)
+        for (wp, wd), (gp, gd) in zip(want, got):
+            assert len(wp) == len(gp)
+            for a, b in zip(wp, gp):
+                assert a.shape == b.shape and np.array_equal(a, b)
+            for a, b in zip(wd, gd):
+                assert a.shape == b.shape and np.array_equal(a, b)
+
+
 def test_plan_sizes_follow_the_arithmetic_mode_and_options():
     """The engine memoises a plan's workspace size per (frames, H, W).  Which layers run merged (the five heads' first
     layers as one 320-channel launch) depends on the arithmetic mode and on options, so the memo must not outlive a

@@ -21,11 +21,12 @@ def main():
     ap.add_argument("--pinned", action="store_true")
     ap.add_argument("--eager", action="store_true", help="batch 1 only: call inference() per frame instead of FrameStream")
     ap.add_argument("--slots", type=int, default=7, help="batch 1 only: FrameStream slots (frames in flight)")
+    ap.add_argument("--in-flight", type=int, default=1, help="batch > 1: batches in flight (pipeline.BatchStream.submit_frames); 1 = inference() per batch")
     ap.add_argument("--match", action="store_true", help="batch 1 only: match every frame against its predecessor on the device")
     ap.add_argument("--semantic", action="store_true", help="with --match: per-class matching (match_semantic)")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
-    from nano_vs_slam_amd.pipeline import FrameStream, inference
+    from nano_vs_slam_amd.pipeline import BatchStream, FrameStream, inference
     from nano_vs_slam_amd.synthetic import spread_state_dict
     net = tiny_factory("S", 28)
     sd = spread_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
@@ -59,6 +60,25 @@ def main():
                           "mode": f"FrameStream (HIP graph replay, {a.slots} pinned slots, "
                                   + ("ONE shared compute stream" if os.environ.get("KP2D_FS_SHARED_STREAM") == "1"
                                      else "a compute stream and workspace per slot") + ")"}))
+        return
+    if a.in_flight > 1:
+        # whole batches, several in flight: the upload of batch n + 1 (the preprocess kernel reading pinned host memory) and the
+        # download of batch n - 1's selected rows run behind batch n's kernels
+        bs = BatchStream(net, slots=a.in_flight, top_k=1000, nn_thresh=0.7, device="cuda:0")
+        for _ in bs.map_frames([src] * 4):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for pts, feat, out in bs.map_frames([src] * a.steps):
+            n += len(pts)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        bs.close()
+        print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. H2D of uint8 frames and D2H of keypoints",
+                          "value": round(a.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "batch": a.batch,
+                          "host_memory": "pinned" if a.pinned else "pageable",
+                          "mode": f"BatchStream.submit_frames, {a.in_flight} batches in flight"}))
         return
     for _ in range(3):
         inference(net, src, None, 0.7, 1000, "cuda:0")
