@@ -386,6 +386,8 @@ class BatchStream:
     ``submit`` orders the slot's work behind everything already queued on the caller's current stream (so ``x`` may
     come from it); ``result`` makes the caller's current stream wait for the slot (no host synchronisation) and
     returns the step's tensors, which stay valid until the slot is submitted again ``slots`` batches later.
+    While a BatchStream is open, run the model only through it: a plain ``net(x)`` in between would take the workspace
+    of the slot submitted last, whose forward may still be running on its own stream (``close()`` first).
     """
 
     def __init__(self, net, slots=2, top_k=1000, nn_thresh=0.7, device="cuda", select=True):
