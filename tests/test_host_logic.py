@@ -222,3 +222,41 @@ def test_warp_specialised_conv_kernels_compile_without_spills_and_keep_their_cou
             assert all(ln.endswith("lds") for ln in tail[:4]), tail[:4]     # (nine pieces per wave at 64 channels, five / four at 32)
         checked += 1
     assert checked == 8
+
+
+def test_no_wide_buffer_store_carries_its_offset_in_an_sgpr(tmp_path):
+    """The gfx950 store hazard of DESIGN.md §4 (profiles/r4_wsm_store_hazard.txt): a `buffer_store_dwordx{2,3,4}` whose
+    `soffset` operand is an SGPR gets no wait state from hipcc before the next VALU write of its data registers (LLVM's
+    hazard rule exempts that form), and on gfx950 such a store now and again wrote the NEXT tile's values.  The fix is a
+    code shape (scalar part of the address folded into the VGPR offset, soffset = 0), so this test reads the shipped
+    code objects: every multi-dword buffer store of every kernel in libkp2d_hip.so must have a literal soffset.
+    Disassembles the in-tree library (no GPU, no recompilation)."""
+    import re
+    import shutil
+    import subprocess
+    from nano_vs_slam_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or libkp2d_hip.so not found")
+    so = tmp_path / "libkp2d_hip.so"
+    shutil.copy(_lib.LIB_PATH, so)                                # (--offloading unbundles next to its input)
+    subprocess.run([objdump, "--offloading", so.name], check=True, capture_output=True, cwd=tmp_path, timeout=300)
+    bundles = sorted(p for p in os.listdir(tmp_path) if "amdgcn" in p and "gfx950" in p)
+    assert bundles, os.listdir(tmp_path)
+    stores = bad = 0
+    for b in bundles:
+        asm = subprocess.run([objdump, "-d", b], check=True, capture_output=True, cwd=tmp_path, timeout=300, text=True).stdout
+        for ln in asm.splitlines():
+            m = re.search(r"\bbuffer_store_dwordx[234]\s+([^/]*)", ln)
+            if not m:
+                continue
+            ops = [o.strip() for o in m.group(1).split(",")]
+            # vdata, vaddr | off, srsrc, soffset [offen] [offset:N] ...
+            assert len(ops) >= 4, ln
+            soffset = ops[3].split()[0]
+            stores += 1
+            if not re.fullmatch(r"-?\d+|0x[0-9a-fA-F]+", soffset):
+                bad += 1
+                print("SGPR soffset:", ln.strip())
+    assert stores > 300, stores                                   # the conv epilogues alone hold several hundred
+    assert bad == 0, f"{bad} of {stores} wide buffer stores carry an SGPR soffset"
