@@ -18,6 +18,7 @@ fallback path.
 from __future__ import annotations
 
 import copy
+import contextlib
 import ctypes as C
 import inspect
 import weakref
@@ -325,6 +326,7 @@ class _Engine:
         _lib.check(self.lib.kp2d_create(C.byref(cfg), C.byref(self.handle)))
         self.device = cfg.device
         self._ws = None
+        self._ws_call = None               # a caller's own workspace for the forwards inside using_workspace()
         self.signature = None
 
     def __del__(self):
@@ -356,9 +358,26 @@ class _Engine:
         need = self.lib.kp2d_workspace_bytes(self.handle, B, H, W)
         if need == 0:
             _lib.check(-1 if not self.lib.kp2d_last_error() else -5)
+        if self._ws_call is not None:
+            if self._ws_call.numel() < need or self._ws_call.device != device:
+                raise RuntimeError(f"using_workspace(): the buffer holds {self._ws_call.numel()} bytes on {self._ws_call.device}, "
+                                   f"the forward needs {need} on {device}")
+            return self._ws_call
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
+
+    @contextlib.contextmanager
+    def using_workspace(self, ws):
+        """Forwards enqueued inside the block take `ws` (a uint8 device tensor of at least kp2d_workspace_bytes) instead of
+        the engine's cached workspace, which stays untouched: streams that keep several forwards in flight (pipeline.
+        FrameStream / BatchStream) give every slot its own buffer this way, and a plain ``net(x)`` beside them keeps the
+        engine's — it can never land on a buffer a slot's kernels are still using."""
+        prev, self._ws_call = self._ws_call, ws
+        try:
+            yield
+        finally:
+            self._ws_call = prev
 
 
 def _ptr(t):

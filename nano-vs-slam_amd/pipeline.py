@@ -193,19 +193,19 @@ class FrameStream:
         if self._slot_ws[slot] is None:
             need = eng.lib.kp2d_workspace_bytes(eng.handle, 1, self.H, self.W)
             self._slot_ws[slot] = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.dev)
-        eng._ws = self._slot_ws[slot]
-        if _fused_front(self.net) and not self.zero_copy:
-            # frame in device memory: the first layer reads it (kp2d_forward_frames)
-            fwd = self.net.forward_frames(self.dev_in[slot], (self.H, self.W))
-        else:
-            # zero-copy slot (pinned host memory): ONE pass over PCIe by the preprocess kernel; the fused first layer
-            # would fetch every halo / bilinear tap across the bus again
-            x = torch.empty(1, 3, self.H, self.W, device=self.dev)
-            stream = torch.cuda.current_stream(self.dev).cuda_stream
-            Hs, Ws = self.dev_in[slot].shape[1:3]
-            _lib.check(lib.kp2d_preprocess(C.c_void_p(self.dev_in[slot].data_ptr()), 1, Hs, Ws, C.c_void_p(x.data_ptr()),
-                                           self.H, self.W, C.c_void_p(stream)))
-            fwd = self.net(x)
+        with eng.using_workspace(self._slot_ws[slot]):
+            if _fused_front(self.net) and not self.zero_copy:
+                # frame in device memory: the first layer reads it (kp2d_forward_frames)
+                fwd = self.net.forward_frames(self.dev_in[slot], (self.H, self.W))
+            else:
+                # zero-copy slot (pinned host memory): ONE pass over PCIe by the preprocess kernel; the fused first layer
+                # would fetch every halo / bilinear tap across the bus again
+                x = torch.empty(1, 3, self.H, self.W, device=self.dev)
+                stream = torch.cuda.current_stream(self.dev).cuda_stream
+                Hs, Ws = self.dev_in[slot].shape[1:3]
+                _lib.check(lib.kp2d_preprocess(C.c_void_p(self.dev_in[slot].data_ptr()), 1, Hs, Ws, C.c_void_p(x.data_ptr()),
+                                               self.H, self.W, C.c_void_p(stream)))
+                fwd = self.net(x)
         out = self.net.post_processing(fwd, self.H, self.W)
         from .selectors import _cap, select_and_gather
         idx, _val, cnt, pts, dsel = select_and_gather(out["score"], out["coord"], out["feat"], _cap(self.top_k, out["score"]),
@@ -368,8 +368,8 @@ class FrameStream:
 
 class BatchStream:
     """Whole batches through the network with ``slots`` batches in flight (throughput path; the batched counterpart of
-    ``FrameStream``).  The reference evaluates batches one after the other (``model(x)`` in a loop,
-    src/kp2dtiny/evaluation.py:95-140, src/train_tiny.py validation); on one stream every layer of batch n + 1 waits for
+    ``FrameStream``).  The reference evaluates batches one after the other (``model(x)`` per batch of the data loader,
+    src/evaluation/keypoints.py:102-108, src/evaluation/segmentation.py:38-40); on one stream every layer of batch n + 1 waits for
     the last workgroup of batch n's last kernel, and inside a batch every launch has a tail in which most of the chip
     idles.  Here consecutive batches alternate over ``slots`` HIP streams, each with its own engine workspace, and the
     engine runs each forward as ONE stream lane (``kp2d_set_option("lanes", 1)``): the two batches in flight are at
@@ -385,9 +385,13 @@ class BatchStream:
 
     ``submit`` orders the slot's work behind everything already queued on the caller's current stream (so ``x`` may
     come from it); ``result`` makes the caller's current stream wait for the slot (no host synchronisation) and
-    returns the step's tensors, which stay valid until the slot is submitted again ``slots`` batches later.
-    While a BatchStream is open, run the model only through it: a plain ``net(x)`` in between would take the workspace
-    of the slot submitted last, whose forward may still be running on its own stream (``close()`` first).
+    returns the step's tensors, which stay valid until the slot is submitted again ``slots`` batches later: work the
+    caller enqueues on its current stream before that submit sees them intact (``submit`` / ``submit_frames`` order the
+    slot's stream behind the caller's); reads from any other stream need their own event.
+    Every slot's forward runs on the slot's OWN workspace (``_Engine.using_workspace``); the engine's cached workspace is
+    never touched, so a plain ``net(x)`` / ``inference()`` while batches are in flight is safe (it runs as one lane until
+    ``close()``: same results, the lane count changes no arithmetic).  Use it as a context manager, or call ``close()``,
+    to give the engine its default lane count back; ``__del__`` does so as a last resort.
     """
 
     def __init__(self, net, slots=2, top_k=1000, nn_thresh=0.7, device="cuda", select=True):
@@ -403,18 +407,43 @@ class BatchStream:
         self._pin_out, self._held = {}, {}
         self._n = 0
         self._eng = net._get_engine(self.dev)
+        self._open = True
         if self.slots > 1:       # several forwards side by side: each as one lane (see the class comment)
+            if getattr(self._eng, "_batch_stream_open", False):
+                raise RuntimeError("another BatchStream is open on this model: close() it first")
+            self._eng._batch_stream_open = True
             _lib.check(self._eng.lib.kp2d_set_option(self._eng.handle, b"lanes", 1))
 
     def close(self):
-        """Back to the engine's default lane count (for callers that go on with plain ``net(x)``)."""
+        """Wait for the slots and give the engine its default lane count back."""
+        if not self._open:
+            return
+        self._open = False
         torch.cuda.synchronize(self.dev)
         if self.slots > 1:
+            self._eng._batch_stream_open = False
             _lib.check(self._eng.lib.kp2d_set_option(self._eng.handle, b"lanes", 0))
-        self._eng._ws = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_open(self):
+        if not self._open:
+            raise RuntimeError("BatchStream is closed")
 
     def submit(self, x: torch.Tensor) -> int:
         from .selectors import _cap, select_and_gather
+        self._check_open()
         slot = self._n % self.slots
         self._n += 1
         st = self.streams[slot]
@@ -423,9 +452,8 @@ class BatchStream:
         need = int(self._eng.lib.kp2d_workspace_bytes(self._eng.handle, B, H, W))
         if self._ws[slot] is None or self._ws[slot].numel() < need:
             self._ws[slot] = torch.empty(max(need, 256), dtype=torch.uint8, device=self.dev)
-        with torch.cuda.stream(st), torch.no_grad():
+        with torch.cuda.stream(st), torch.no_grad(), self._eng.using_workspace(self._ws[slot]):
             x.record_stream(st)
-            self._eng._ws = self._ws[slot]          # the forward takes the engine's cached workspace: this slot's own
             out = self.net.post_processing(self.net(x), H, W)
             if self.select:
                 _idx, _val, cnt, pts, desc = select_and_gather(out["score"], out["coord"], out["feat"],
@@ -452,9 +480,12 @@ class BatchStream:
         t = _as_frames(frames)
         if t.device.type != "cpu":
             raise ValueError("submit_frames takes host frames (device tensors: forward_frames / submit)")
+        self._check_open()
         slot = self._n % self.slots
         self._n += 1
         st = self.streams[slot]
+        # the slot's previous tensors may still be read by work on the caller's stream (see the class comment)
+        st.wait_stream(torch.cuda.current_stream(self.dev))
         B, Hs, Ws, _ = t.shape
         H, W = (Hs, Ws) if new_size is None else (int(new_size[0]), int(new_size[1]))
         zero_copy = _pinned_zero_copy(t)
@@ -462,8 +493,7 @@ class BatchStream:
         need = int(self._eng.lib.kp2d_workspace_bytes(self._eng.handle, B, H, W))
         if self._ws[slot] is None or self._ws[slot].numel() < need:
             self._ws[slot] = torch.empty(max(need, 256), dtype=torch.uint8, device=self.dev)
-        with torch.cuda.stream(st), torch.no_grad():
-            self._eng._ws = self._ws[slot]
+        with torch.cuda.stream(st), torch.no_grad(), self._eng.using_workspace(self._ws[slot]):
             if zero_copy or not _fused_front(self.net):
                 if not zero_copy:
                     t = t.to(self.dev, non_blocking=True)

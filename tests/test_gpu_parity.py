@@ -1369,6 +1369,48 @@ def test_batch_stream_equals_the_plain_loop(slots):
     assert torch.equal(again["score"], want[0][0]["score"])
 
 
+def test_plain_forward_beside_an_open_batch_stream_keeps_its_own_workspace():
+    """A plain net(x) while a BatchStream has batches in flight: every slot forwards on its OWN workspace
+    (_Engine.using_workspace) and the engine's cached one is never pointed at a slot's buffer (rounds 3-4 swapped
+    eng._ws, so such a forward took the last slot's scratch memory while that slot's kernels were still running).
+    Both the in-flight batches and the plain forwards must equal the plain loop bit for bit; a second BatchStream on the
+    same model is refused, a closed one refuses submits, and the context-manager form restores the lane count."""
+    from nano_vs_slam_amd.pipeline import BatchStream
+    model, _ = product_model("S", False, 28)
+    H, W = 96, 128
+    batches = [torch.from_numpy(synthetic_frames(6, H, W, seed=60 + i)).to(DEV) for i in range(4)]
+    other = torch.from_numpy(synthetic_frames(5, H, W, seed=70)).to(DEV)
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in model.post_processing(model(x), H, W).items() if torch.is_tensor(v)} for x in batches]
+        want_other = model(other)["feat"].clone()
+    eng = model._get_engine(torch.device(DEV))
+    with BatchStream(model, slots=2, top_k=300, device=DEV) as bs:
+        with pytest.raises(RuntimeError):
+            BatchStream(model, slots=2, device=DEV)
+        slots = []
+        for i, x in enumerate(batches):
+            slots.append(bs.submit(x))
+            with torch.no_grad():
+                got_other = model(other)["feat"]             # plain forward on the caller's stream, slots in flight
+            assert all(eng._ws is not w for w in bs._ws if w is not None)
+            assert eng._ws_call is None
+            assert torch.equal(got_other, want_other), i
+            if len(slots) == 2:
+                out = bs.result(slots.pop(0))[0]
+                j = i - 1
+                for k in want[j]:
+                    assert torch.equal(out[k], want[j][k]), (j, k)
+        while slots:
+            out = bs.result(slots.pop(0))[0]
+            for k in want[-1]:
+                assert torch.equal(out[k], want[-1][k]), k
+    with pytest.raises(RuntimeError):
+        bs.submit(batches[0])
+    bs2 = BatchStream(model, slots=2, device=DEV)          # the first one is closed: allowed again
+    bs2.close()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("semantic", [False, True])
 def test_frame_stream_matches_consecutive_frames_on_the_device(semantic):
     """FrameStream(match=True): the VO loop's matcher inside the replayed graphs (visual_odometry.py:193-284 / :347-380).
