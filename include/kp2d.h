@@ -157,6 +157,11 @@ int kp2d_preprocess(const uint8_t* frames, int B, int Hs, int Ws, float* x, int 
  *   d0 [B,max0,C] query descriptors, n0 [B] valid rows; d1 [B,max1,C] train descriptors, n1 [B]; C in {32,64,128}
  *   nn_idx / nn_dist / nn_dist2 [B,max0]  nearest train row, its L2 distance, second-nearest distance
  *     (nn_idx alone = cv2.BFMatcher(NORM_L2, crossCheck=False).match, src/evaluation/descriptor.py:132-134)
+ *     For ANY finite input: with >= 256 train rows the search ranks on split-fp16 matrix-core keys and decides on an
+ *     exact pass, which needs every row's norm in [0.5, 2^15] (unit-norm descriptors are); a workgroup that meets a
+ *     row outside that range scans its rows with the exact arithmetic instead (slower, same answer).  On equal fp32
+ *     distances the lower train index wins, except that among THREE train rows within ~1e-6 of each other (not
+ *     identical) the matrix-core form may return either of the two nearest as nn_idx; nn_dist / nn_dist2 are exact.
  *   match_q [B,max1]  the query kept for each train row after ratio test + one-to-one filtering (-1: none)
  *   match_d [B,max1]  its distance
  *   scratch: B*max1*8 bytes of device memory */

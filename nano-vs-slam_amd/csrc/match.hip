@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ d0,
 // nearest / second-nearest are taken by (exact distance, lower index).  So nn_dist / nn_dist2 are bit-identical to the
 // VALU kernel's, and nn_idx differs from it only if three train rows of one lane's half lie within ~1e-6 of each other
 // without being identical (identical rows have identical keys and keep their index order).
+// Precondition of the ranking, checked in the kernel: every row's norm in [0.5, 2^15].  A workgroup that sees a row outside
+// it (descriptors scaled by 1e5 or 1e-6, an all-zero row) falls back to an exact scan of its slice — any input gets the
+// VALU kernel's answer, the matrix cores only ever make the in-range case fast.
 // A workgroup = four waves x 32 queries against the same LDS tiles of train rows.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 mh8 __attribute__((ext_vector_type(8)));
@@ -181,6 +184,23 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const float* __restrict_
     ql[s] = mh8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
   }
   const int qc = MASKED ? c0[(size_t)b * max0 + (q < n0 ? q : 0)] : 0;
+  // Range guard.  The split-fp16 keys rank well only while a row's hi halves are normal fp16 numbers with their lo halves
+  // above the subnormal floor, and below the clamp of FP16_OVFL: rows with |row| outside [0.5, 2^15] (unit-norm descriptors
+  // sit in the middle of it) would rank on saturated or vanished keys and the exact pass would then re-score the wrong
+  // candidates.  A workgroup that meets such a row — among its queries or in its slice of the train rows — discards its
+  // ranking and scans its slice with the exact arithmetic instead (slow, correct; below).
+  auto norm_ok = [](float n2) { return n2 >= 0.25f && n2 <= 1073741824.f; };
+  bool bad = false;
+  {
+    float qn = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * h), v1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * h + 4);
+      qn += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+    }
+    qn += __shfl_xor(qn, 32);
+    bad = q < n0 && !norm_ok(qn);
+  }
   float best = INFINITY, second = INFINITY;          // approximate keys |t|^2 - 2 q.t of this lane's half of the train rows
   int bi = -1, si = -1;
   constexpr int LPR = C / 4;                          // lanes per train row in the staging loop (a float4 each)
@@ -198,6 +218,7 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const float* __restrict_
       float nn = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
 #pragma unroll
       for (int o = 1; o < LPR; o <<= 1) nn += __shfl_xor(nn, o);
+      bad |= row < nt && !norm_ok(nn);
       if (c4 == 0) {
         s_n[row] = row < nt ? nn : INFINITY;          // rows past the range can never be a neighbour
         if (MASKED) s_c[row] = row < nt ? c1[(size_t)b * max1 + t0 + row] : -1;
@@ -252,6 +273,19 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const float* __restrict_
   int i1 = bi, i2 = si;
   auto before = [](float da, int ia, float db, int ib) { return ib < 0 || (ia >= 0 && (da < db || (da == db && ia < ib))); };
   if (!before(e1, i1, e2, i2)) { const float te = e1; e1 = e2; e2 = te; const int ti = i1; i1 = i2; i2 = ti; }
+  if (__syncthreads_or(bad ? 1 : 0)) {
+    // a row outside the range guard: this lane's half of the workgroup's train slice, every row with the exact arithmetic
+    const int mid = t_lo + ((t_hi - t_lo + 1) >> 1);
+    const int s0 = h == 0 ? t_lo : mid, s1 = h == 0 ? mid : t_hi;
+    e1 = e2 = INFINITY;
+    i1 = i2 = -1;
+    for (int t = s0; t < s1; ++t) {
+      if (MASKED && c1[(size_t)b * max1 + t] != qc) continue;
+      const float d = exact(t);
+      if (before(d, t, e1, i1)) { e2 = e1; i2 = i1; e1 = d; i1 = t; }
+      else if (before(d, t, e2, i2)) { e2 = d; i2 = t; }
+    }
+  }
   // merge with the other half of the train rows (lane ^ 32): two sorted pairs -> the two smallest by (distance, index)
   const float f1 = __shfl_xor(e1, 32), f2 = __shfl_xor(e2, 32);
   const int k1 = __shfl_xor(i1, 32), k2 = __shfl_xor(i2, 32);

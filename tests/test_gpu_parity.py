@@ -1208,6 +1208,53 @@ def test_descriptor_matching_widths_and_sliced_search(C):
         _pairs_equal(rs["match_q"][b].cpu().numpy(), best, dd1, dd2, 0.7)
 
 
+@pytest.mark.parametrize("scale", [1e5, 1e-6, "mixed"])
+def test_descriptor_matching_outside_the_fp16_range_of_the_matrix_core_search(scale):
+    """The matrix-core search ranks on split-fp16 keys: descriptors scaled by 1e5 (past the fp16 clamp) or 1e-6 (hi halves
+    subnormal, lo halves gone) used to rank on saturated / vanished keys and the exact pass then re-scored the wrong
+    candidates, silently.  The kernel now checks every row's norm against [0.5, 2^15] and a workgroup that meets a row
+    outside it scans its slice exactly: nn_idx / nn_dist / nn_dist2 and the matches must equal the oracle (which is
+    scale-invariant up to fp32 rounding) at any scale — also when only SOME rows are out of range ("mixed": one all-zero
+    query, a few huge train rows).  >= 256 train rows, so this is the matrix-core path (KP2D_MATCH_MFMA default)."""
+    from nano_vs_slam_amd.matching import match_descriptors
+    rng = np.random.default_rng(91)
+    B, k0, k1, C = 2, 500, 700, 32
+    d0, d1 = _match_problem(rng, B, k0, k1, C, 200)
+    if scale == "mixed":
+        d0[0, 7] = 0.0
+        d1[0, 100:104] *= np.float32(3e5)
+        d1[1, 650] *= np.float32(1e-7)
+    else:
+        d0 *= np.float32(scale)
+        d1 *= np.float32(scale)
+    n0 = np.array([500, 411], np.int32)
+    n1 = np.array([700, 688], np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    r = match_descriptors(t(d0), t(n0), t(d1), t(n1), 0.7)
+    total = 0
+    for b in range(B):
+        best, nn, dd1, dd2 = orc.bf_match_one_to_one(d0[b, :n0[b]], d1[b, :n1[b]], 0.7)
+        got_nn = r["nn_idx"][b, :n0[b]].cpu().numpy()
+        diff = np.where(got_nn != nn)[0]
+        # a different index only for an exact tie in fp32 (the all-zero query sees many rows at one distance)
+        got_d = r["nn_dist"][b, :n0[b]].cpu().numpy()
+        for q in diff:
+            assert np.isclose(np.sqrt(((d0[b, q] - d1[b, got_nn[q]]) ** 2).sum(dtype=np.float32)), dd1[q], rtol=1e-6), (b, q)
+        assert len(diff) <= 2, diff
+        assert np.allclose(got_d, dd1, rtol=2e-6, atol=0), np.max(np.abs(got_d / dd1 - 1))
+        fin = np.isfinite(dd2)
+        assert np.allclose(r["nn_dist2"][b, :n0[b]].cpu().numpy()[fin], dd2[fin], rtol=2e-6, atol=0)
+        sc = float(np.median(dd1)) if scale == "mixed" else float(scale)
+        got = {int(tt): int(q) for tt, q in enumerate(r["match_q"][b].cpu().numpy()) if q >= 0}
+        want = {tt: q for tt, (q, _) in best.items()}
+        for tt in set(got) ^ set(want):                    # ratio test on its fp32 boundary (relative, any scale)
+            q = got.get(tt, want.get(tt))
+            assert abs(dd1[q] - 0.7 * dd2[q]) < 1e-5 * max(dd1[q], 1e-30) * 10, (tt, q, sc)
+        assert all(got[tt] == want[tt] for tt in set(got) & set(want))
+        total += len(got)
+    assert total > 150, total
+
+
 def test_descriptor_matching_per_class():
     """match_semantic (visual_odometry.py:347-380) as one class-masked launch vs the per-class loop of the oracle: classes
     that are empty on one side, a class with ONE train row (no second neighbour: skipped, as the reference's knnMatch(k=2)
