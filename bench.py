@@ -204,6 +204,11 @@ def self_launch(args):
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
                 LOCAL_WORLD_SIZE=str(args.gpus), KP2D_BENCH_SELF_LAUNCHED="1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    # the N ranks share this host's cores (a GPU box grants ~2 per GPU: 16 for eight ranks that each enqueue ~40 launches per
+    # 2.7 ms step): one rank must not spin up a full-size OpenMP / intra-op pool per process
+    per_rank = max(1, host_cores() // max(1, args.gpus))
+    base.setdefault("OMP_NUM_THREADS", str(per_rank))
+    base.setdefault("MKL_NUM_THREADS", str(per_rank))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(args.gpus):
@@ -245,17 +250,25 @@ def self_launch(args):
 def dry_run(args, rank, world):
     """--dry-run: the launch + rendezvous path only (no device, no kernels, no throughput)."""
     import torch.distributed as dist
-    seen = [rank]
+    from nano_vs_slam_amd.sharding import shard_range
+    gb = args.global_batch if args.global_batch > 0 else world * (args.batch if args.batch > 0 else 64)
+    if gb < world:
+        raise SystemExit("--global-batch must be at least the number of ranks")
+    lo, hi = shard_range(gb, rank, world)               # the frame shard this rank would run
+    mine = torch.tensor([rank, lo, hi, torch.get_num_threads()], dtype=torch.int64)
+    every = [mine]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        mine = torch.tensor([rank], dtype=torch.int64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        seen = sorted(int(v.item()) for v in every)
+    rows = sorted([int(v) for v in e.tolist()] for e in every)
+    seen = [r[0] for r in rows]
     if rank == 0:
         print(json.dumps({"metric": "dry-run (rendezvous only, nothing measured)", "dry_run": True, "value": None,
                           "n_gpus": world, "collective": {"backend": "gloo", "ranks_seen": len(seen), "ranks": seen},
+                          "global_batch": gb, "frame_shards": [[r[1], r[2]] for r in rows],
+                          "host_threads_per_rank": [r[3] for r in rows], "host_cores": host_cores(),
                           "launcher": "self (bench.py started its own ranks)" if os.environ.get("KP2D_BENCH_SELF_LAUNCHED")
                           else "external (torchrun or equivalent)"}), flush=True)
     if world > 1:
@@ -274,6 +287,8 @@ def main():
         # the line's n_gpus must be what was asked for AND what ran: refuse anything else
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with python -m torch.distributed.run "
                          f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}")
+    if world > 1:      # ranks of one node share its cores (self_launch sets OMP_NUM_THREADS too; a launcher may not have)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cores() // world)))
     if args.dry_run:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():

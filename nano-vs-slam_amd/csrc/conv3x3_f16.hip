@@ -368,6 +368,13 @@ constexpr int WS_BARRIERS_PER_TRIP = 2;
 __host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (ntiles - t0 + 2 * G - 1) / (2 * G); }
 }  // namespace
 
+// S16OUT: the pooled output leaves as an S16P tensor (kp2d_kernels.h; its consumer is conv3x3_s16.hip).  The products are
+// then TRANSPOSED (weights = A operand, pixels = B, as conv3x3_wsm.hip): a lane's four accumulator registers are four
+// channels of ONE pixel, the 2 x 2 pooling block is lanes 4 q .. 4 q + 3 (DPP quad maximum), and with the two N-tiles' weight
+// rows interleaved in LDS (N-tile n, row 4 g + i = channel 8 g + 4 n + i) lane group g holds channels 8 g .. 8 g + 7 of its
+// pixel: [8 hi halves] / [8 lo halves] = two 16-byte stores from lane 4 q.  Same products in the same order: the values
+// that are split are bit-identical to those the fp32 form stores.
+template <bool S16OUT>
 __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
@@ -379,9 +386,12 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   constexpr int OOB = 0x7ffffff0;
 
   // weights: the chunk's [slot][n][16 hi | 16 lo] rows -> [wh plane | wl plane] (as the kernel above), once
-  for (int gi = tid; gi < 9 * WS_N * 4; gi += 768)
-    *reinterpret_cast<float4*>(sm + WS_W + (gi >> 2) * 32 + (gi & 1) * 16 + ((gi >> 1) & 1) * WS_WL) =
+  for (int gi = tid; gi < 9 * WS_N * 4; gi += 768) {
+    const int row = gi >> 2, n = row & (WS_N - 1);
+    const int rp = S16OUT ? (row - n) + 16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3) : row;
+    *reinterpret_cast<float4*>(sm + WS_W + rp * 32 + (gi & 1) * 16 + ((gi >> 1) & 1) * WS_WL) =
         reinterpret_cast<const float4*>(a.w)[gi];
+  }
 
   // ---- producer state: granule gi = ptid + 256 it of a halo tile = (halo pixel gi / 4, channels 4 (gi % 4) ..) ----
   const int ptid = tid - 512;
@@ -440,9 +450,14 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   auto tap_off = [](int t) constexpr { return ((t / 3) * WS_PITCH + (t % 3)) * F_PXB; };
   const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
   const int Hp = H >> 1, Wp = W >> 1;
-  float sc[NN], sh[NN];
+  // fp32 form: lane = channel (n 16 + lp) of four pixels; S16P form: lane = pixel, channels 8 lg .. 8 lg + 7
+  constexpr int NSC = S16OUT ? 8 : NN;
+  float sc[NSC], sh[NSC];
 #pragma unroll
-  for (int n = 0; n < NN; ++n) { sc[n] = a.scale[n * 16 + lp]; sh[n] = a.shift[n * 16 + lp]; }
+  for (int n = 0; n < NSC; ++n) {
+    const int c = S16OUT ? 8 * lg + n : n * 16 + lp;
+    sc[n] = a.scale[c]; sh[n] = a.shift[c];
+  }
 
   auto multiply = [&](int t, int buf) {
     const int b = t / per_frame, r = t - b * per_frame;
@@ -475,20 +490,85 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
           const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
+            if constexpr (S16OUT) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], x, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], x, acc[m][n], 0, 0, 0);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
+            }
           }
         } else {
           const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
           const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + WS_LO);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
+            if constexpr (S16OUT) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh, acc[m][n], 0, 0, 0);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
+            }
           }
         }
       }
+    }
+    if constexpr (S16OUT) {
+      // lane (lp, lg): pixel lp of M-tile m = (row (lp >> 1) & 1, column 2 (lp >> 2) + (lp & 1)), channels 8 lg + 4 n + r.
+      // Pooled pixel = the quad of lanes 4 q .. 4 q + 3; lane 4 q stores it (soffset = 0: the gfx950 store hazard,
+      // conv3x3_wsm.hip)
+      const int obs = Hp * Wp * a.cout;                // output frame stride, floats (S16P: the same bytes as fp32 NHWC)
+      const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(a.out1 + (size_t)b * obs, 0, obs * 4, 0x00020000);
+      const int cpart = (lg >> 1) * (Hp * 2 * Wp * 32) + (lg & 1) * 16;
+      const int cinv = (8 * lg < a.cout && (lp & 3) == 0) ? 0 : OOB;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float v[8];
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float tt = fmaf(acc[m][n][r], sc[4 * n + r], sh[4 * n + r]);
+            v[4 * n + r] = fmaxf(tt, tt * slope);
+          }
+        float p[8];
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %2, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %3, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %4, %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %5, %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %6, %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %7, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+        split2(p[0], p[1], h0, l0);
+        split2(p[2], p[3], h1, l1);
+        split2(p[4], p[5], h2, l2);
+        split2(p[6], p[7], h3, l3);
+        const i32x4 hi = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+        const i32x4 lo = {__builtin_bit_cast(int, l0), __builtin_bit_cast(int, l1), __builtin_bit_cast(int, l2), __builtin_bit_cast(int, l3)};
+        const int yp = (y0 + wr * 4 + 2 * (m / CB)) >> 1, xp = ((x0 + 16 * ph + 8 * (m % CB)) >> 1) + (lp >> 2);
+        const int inv = ((yp < Hp && xp < Wp) ? 0 : OOB) | cinv;
+        const int o = (yp * 2 * Wp + xp) * 32 + cpart;
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rso, o | inv, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rso, (o + Wp * 32) | inv, 0, 0);
+      }
+      return;
     }
     // pooled epilogue (conv_epilogue.inc, ST_NHWC_POOL): the four registers of a lane are one 2 x 2 pixel block
     unsigned* o1 = reinterpret_cast<unsigned*>(a.out1) + (size_t)b * Hp * Wp * a.os1;
@@ -560,18 +640,31 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   }
 }
 
+template <bool S16OUT>
 static int launch_ws(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   a.tiles_x = (a.W + WS_TW - 1) / WS_TW;
   a.tiles_y = (a.H + WS_TH - 1) / WS_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   static PerDeviceOnce lds_once;
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel))) return e;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel<S16OUT>))) return e;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    else (void)hipGetLastError();
+    return n > 0 ? n : 256;
+  }();
   const int grid = (int)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel, dim3(grid), dim3(768), WS_LDS, s, a, (int)ntiles);
+  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel<S16OUT>, dim3(grid), dim3(768), WS_LDS, s, a, (int)ntiles);
   return (int)hipGetLastError();
+}
+
+// the map-side conditions of the warp-specialised conv1b form (the layer-side ones — 16 -> 32 channels, pooled — are the
+// caller's): the plan asks before it decides to keep conv1b's output split (ST_S16P_POOL has no other producer)
+static const bool ws_on = !(getenv("KP2D_WS") && getenv("KP2D_WS")[0] == '0');
+bool conv3x3_ws_would_run(int B, int H, int W, int ws_min) {
+  return ws_on && !(H & 1) && !(W & 1) && W >= 32 && (long)((W + 31) / 32) * ((H + 15) / 16) * B >= (ws_min > 0 ? ws_min : 1024) &&
+         (long)B * H * W * 16 * 4 < 0x7ffffff0L;
 }
 
 template <int NH, int NP, int TH = TILE, bool FLAT32 = false>
@@ -604,6 +697,15 @@ void conv3x3_note_variant(const char* v) { g_variant = v; }
 
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.taps != 9 || a.prec != 1) return -1000;
+  // S16P tensors (kp2d_kernels.h): read only by conv3x3_s16.hip, written by it and by the conv1b form below
+  if (a.in0.fmt == 1) return launch_conv3x3_f16x3_s16(a, s);
+  if (a.store == ST_S16P) return -1006;
+  if (a.store == ST_S16P_POOL) {
+    if (!(a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.cout == 32 && a.act <= ACT_RELU &&
+          a.in0.rs == (long)a.W * a.in0.ps && a.in0.ps == 16 && a.in0.o == 0 && conv3x3_ws_would_run(a.B, a.H, a.W, a.ws_min))) return -1006;
+    g_variant = "<ws>s16";
+    return launch_ws<true>(a, s);
+  }
   // the staging addresses a source pixel as (y * W + x) * pixel stride
   if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return -1004;
   if ((long)a.H * a.W * (a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps) * 4 >= 0x7ffffff0L) return -1002;
@@ -626,11 +728,10 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   // 32-channel layers on grids that fill the chip anyway: 16 x 32 pixel tiles (one weight slab per 512 pixels, 16 waves
   // per CU).  Small grids keep the 16 x 16 tiles (twice the workgroups, half as long: single frames).  KP2D_WIDE=0: never.
   // single-chunk, max-pooled, 32 channels (conv1b) on grids that fill the chip several times: warp-specialised persistent form
-  static const bool ws_on = !(getenv("KP2D_WS") && getenv("KP2D_WS")[0] == '0');
   if (ws_on && a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.store == ST_NHWC_POOL && a.act <= ACT_RELU &&
       !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= (a.ws_min > 0 ? a.ws_min : 1024) &&
       (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
-  { g_variant = "<ws>"; return launch_ws(a, s); }
+  { g_variant = "<ws>"; return launch_ws<false>(a, s); }
   // 32-channel layers on grids that fill the chip several times: the warp-specialised persistent form with 32-channel items
   if (a.npad == 32 && !a.ng32) {
     const int e = launch_conv3x3_f16x3_wsm(a, s, 32);

@@ -124,6 +124,7 @@ struct Act {
   size_t off = 0, bytes = 0;
   int C = 0, H = 0, W = 0;
   int PS = 0, CO = 0;  // channel-slice view of a wider tensor: pixel stride (0 = C) and first channel; bytes = 0 (not owned)
+  int fmt = 0;         // 1: an S16P tensor (kp2d_kernels.h: the fp16 halves of the split, planar rows; same bytes), never a view
 };
 
 }  // namespace
@@ -147,6 +148,7 @@ struct kp2d_model {
   int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
   int wsm_tr = 0;         // kp2d_set_option("wsm_transposed")
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
+  int s16_min = 0;        // kp2d_set_option("s16_min_items"): conv3x3_s16.hip — 0 = automatic (three rounds of tiles per workgroup), N = from N tiles, < 0 = never
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
   int lanes = 2;          // independent sub-batches run concurrently on this many HIP streams (KP2D_LANES); +3 %
@@ -599,7 +601,8 @@ struct Plan {
     if (dry || rc != KP2D_OK || !m->tap_dst || name != m->tap_name) return;
     const size_t per = (size_t)a.C * a.H * a.W;
     if (((size_t)b0 + B) * per > m->tap_cap) { rc = fail(KP2D_ERR_ARG, "tap '%s': buffer holds %zu floats, needs %zu", name.c_str(), m->tap_cap, ((size_t)b0 + B) * per); return; }
-    check(launch_nhwc_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H * a.W, a.PS ? a.PS : a.C, a.CO, stream), name.c_str());
+    if (a.fmt == 1) check(launch_s16p_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H, a.W, stream), name.c_str());
+    else check(launch_nhwc_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H * a.W, a.PS ? a.PS : a.C, a.CO, stream), name.c_str());
   }
 
   Act alloc(int C, int H_, int W_) {
@@ -645,6 +648,7 @@ struct Plan {
     const int ps = t.PS ? t.PS : t.C;
     s.p = p; s.c = c; s.o = o + t.CO;
     s.ps = ps; s.rs = (long)t.W * ps; s.bs = (long)t.H * t.W * ps;
+    s.fmt = t.fmt;
     return s;
   }
   // arguments of one conv launch; false (rc set) when the plan and the layer disagree
@@ -662,6 +666,7 @@ struct Plan {
     a.wsm_tr = m->wsm_tr;
     a.ws_min = m->ws_min;
     a.wsm_lanes = nlanes;
+    a.s16_min = m->s16_min;
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.w_tr = (split && c.w16t_off) ? m->blob + c.w16t_off : nullptr;
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
@@ -669,7 +674,7 @@ struct Plan {
     // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
     // (a forced warp-specialised form — kp2d_set_option("wsm_min_items"), the parity tests — keeps its 64-channel groups)
     const bool wsm_forced = m->wsm_min > 0 && (long)((Wc + 31) / 32) * ((Hc + 15) / 16) * B * (c.npad / 64) >= m->wsm_min;
-    if (split && c.npad >= 64 && m->small_grid_ng32 && !wsm_forced &&
+    if (split && c.npad >= 64 && m->small_grid_ng32 && !wsm_forced && s0.fmt == 0 &&      // (an S16P input: conv3x3_s16.hip, 64-channel groups)
         (long)a.tiles_x * a.tiles_y * B * (c.npad / 64) < 256) {
       a.w = m->blob + c.w16n_off;
       a.ng32 = 1;
@@ -838,6 +843,14 @@ struct Plan {
       *pooled = alloc(c.cout, Hc / 2, Wc / 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, dry ? nullptr : ptr(*pooled),
            c.cout, 0, 0, Hc, Wc);
+    } else if (store == ST_S16P) {
+      out = alloc(c.cout, Hc, Wc);
+      out.fmt = 1;
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, nullptr, 0, 0, 0, Hc, Wc);
+    } else if (store == ST_S16P_POOL) {
+      out = alloc(c.cout, Hc / 2, Wc / 2);
+      out.fmt = 1;
+      conv(name, in0, in0.C, 0, in1, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, Hc, Wc);
     } else {  // ST_SHUFFLE
       out = alloc(c.cout / 4, Hc * 2, Wc * 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
@@ -879,13 +892,21 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.prof_end();
   }
   P.tap("backbone.conv1a", t1a);
-  Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC);
+  // The 32-channel stage conv1b -> conv2a -> conv2b -> conv3a -> conv3b with its four inner tensors kept SPLIT (S16P,
+  // kp2d_kernels.h): the consumers copy their operand images HBM -> LDS without a vector instruction (conv3x3_s16.hip; these
+  // layers are bound by HBM and by their staging, not by the matrix cores).  Same values bit for bit.  Decided here, for
+  // the whole chain, because the layout has exactly one reader and two writers: S configs (16 -> 32 -> 32 -> 32 -> 64, two
+  // pools), split-fp16 arithmetic, and a grid big enough for the persistent forms of both ends.
+  const bool s16 = m->precision == KP2D_PREC_F16X3 && g.downsample == 2 && m->c1 == 16 && m->c2 == 32 && m->c3 == 32 && m->c4 == 64 &&
+                   m->s16_min >= 0 && conv3x3_ws_would_run(B, H, W, m->ws_min) &&
+                   conv3x3_s16_would_run(B, H / 2, W / 2, P.nlanes, m->s16_min, m->wsm_grid);
+  Act p1 = P.cbr("backbone.conv1b", t1a, nullptr, s16 ? ST_S16P_POOL : (g.downsample >= 2 ? ST_NHWC_POOL : ST_NHWC));
   P.release(t1a);
-  Act t2a = P.cbr("backbone.conv2a", p1, nullptr, ST_NHWC);
+  Act t2a = P.cbr("backbone.conv2a", p1, nullptr, s16 ? ST_S16P : ST_NHWC);
   P.release(p1);
-  Act t2b = P.cbr("backbone.conv2b", t2a, nullptr, g.downsample >= 3 ? ST_NHWC_POOL : ST_NHWC);
+  Act t2b = P.cbr("backbone.conv2b", t2a, nullptr, s16 ? ST_S16P : (g.downsample >= 3 ? ST_NHWC_POOL : ST_NHWC));
   P.release(t2a);
-  Act t3a = P.cbr("backbone.conv3a", t2b, nullptr, ST_NHWC);
+  Act t3a = P.cbr("backbone.conv3a", t2b, nullptr, s16 ? ST_S16P : ST_NHWC);
   P.release(t2b);
   Act xp{};
   Act skip = P.cbr("backbone.conv3b", t3a, nullptr, ST_NHWC_BOTH, &xp);   // downsample >= 1 always
@@ -1569,6 +1590,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "wsm_min_items") {
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "wsm_min_items out of range");
     m->wsm_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "s16_min_items") {     // conv3x3_s16.hip (split activations through the backbone's 32-channel stage): 0 automatic, N from N tiles, -1 never
+    if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "s16_min_items out of range");
+    m->s16_min = (int)value;
     return KP2D_OK;
   }
   if (k == "ws_min_tiles") {

@@ -24,13 +24,19 @@ enum Store : int {
   ST_NHWC_BOTH = 2,        // out0 full-res AND out1 pooled (conv3b: skip + x)
   ST_SHUFFLE = 3,          // PixelShuffle(2) folded into the store: out0 is the 2H x 2W NHWC tensor
   ST_NCHW = 4,             // API-facing planar output; channels [0,nsplit) -> out0, [nsplit,cout) -> out1
+  ST_S16P = 5,             // out0 is an S16P tensor (below), full resolution
+  ST_S16P_POOL = 6,        // out1 = MaxPool2d(2,2) of the activation as an S16P tensor (conv1b)
 };
+// S16P ("split, planar rows"): an activation kept as the fp16 halves the split-fp16 kernels multiply, x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi) — per frame [C / 16 chunks][H][plane: hi | lo][W][16 halves], the same bytes as fp32 NHWC.
+// A tile row of one plane is contiguous, so the consumer copies its LDS operand image straight from HBM (conv3x3_s16.hip).
+// Only between layers of one forward (workspace tensors of the backbone's 32-channel stage); C a multiple of 16.
 
 // One 3x3 / stride 1 / pad 1 (taps = 9) or 1x1 (taps = 1) convolution over an NHWC activation that may be
 // the channel-concat of two tensors (torch.cat([up, skip], 1): heads.py:99, segmentation.py:141,149).
 // A source is addressed as ptr + b*bs + y*rs + x*ps + o + c, so strided views work too: the 2x2 stride-2
 // to_kv conv (modules/segformer.py:93-95) is a 1x1 conv over two row-views of the full-resolution tensor.
-struct ConvSrc { const float* p; int c, o; long bs, rs, ps; };   // channels taken, first channel, strides (floats)
+struct ConvSrc { const float* p; int c, o; long bs, rs, ps; int fmt; };   // channels taken, first channel, strides (floats); fmt 1: an S16P tensor (bs only)
 struct ConvArgs {
   ConvSrc in0, in1;
   int taps;                           // 9 or 1
@@ -52,6 +58,7 @@ struct ConvArgs {
   long long* ids_out;                 // ST_NCHW, one channel group: also write argmax over the stored channels per pixel, [B][H][W] int64 (nullptr: no)
   int ws_min;                         // least tiles for the warp-specialised conv1b form (0: 1024)
   int wsm_grid;                       // most workgroups of that form per launch; 0: KP2D_WSM_GRID or one per CU
+  int s16_min;                        // conv3x3_s16.hip: least work items for the form (0: automatic, three rounds per workgroup)
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
 
@@ -75,6 +82,13 @@ int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: ta
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
 // conv3x3_wsm.hip: the same layers, 64-channel groups, warp-specialised and persistent; -1000 = not eligible / fewer than min_items work items
 int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s, int n_item);   // n_item: 64 (64-channel groups) or 32 (32-channel layers)
+// conv3x3_s16.hip: 32-input-channel layers whose input is an S16P tensor (in0.fmt == 1); -1000: in0 is not S16P
+int launch_conv3x3_f16x3_s16(const ConvArgs& a, hipStream_t s);
+// would that form run for a B x H x W map (the plan decides the activation layout of conv1b .. conv3a's outputs by it)
+bool conv3x3_s16_would_run(int B, int H, int W, int lanes, int min_items, int grid_opt);
+// would the warp-specialised conv1b form (conv3x3_f16.hip, the only producer of a pooled S16P tensor) run
+bool conv3x3_ws_would_run(int B, int H, int W, int ws_min);
+int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);   // kp2d_set_tap on an S16P tensor
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {

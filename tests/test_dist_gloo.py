@@ -136,6 +136,26 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_around():
     assert j["collective"]["ranks"] == [0, 1] and j["launcher"].startswith("self")
 
 
+def test_bench_eight_rank_launch_shards_256_frames_and_caps_host_threads():
+    """BASELINE cfg 3 as the driver would start it on an 8-GPU node — `python bench.py --gpus 8 --global-batch 256` — through
+    --dry-run (no GPU here): eight children, ONE line, every rank seen, contiguous shards of 32 frames that tile the batch,
+    and every rank's host thread pool capped at cores // 8 (eight Python ranks share the node's cores)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "OMP_NUM_THREADS")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--global-batch", "256", "--dry-run"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 8 and j["collective"]["ranks_seen"] == 8
+    assert j["collective"]["ranks"] == list(range(8)) and j["global_batch"] == 256
+    assert j["frame_shards"] == [[32 * i, 32 * (i + 1)] for i in range(8)]
+    cap = max(1, j["host_cores"] // 8)
+    assert all(1 <= t <= cap for t in j["host_threads_per_rank"]), (j["host_threads_per_rank"], cap)
+
+
 def test_bench_self_launch_reports_a_failing_rank():
     """No device here: the real (non-dry) run must fail in every child and the parent must return non-zero, not hang."""
     import subprocess

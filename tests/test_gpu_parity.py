@@ -1086,6 +1086,61 @@ def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3,
         assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()), wsm_layers)
 
 
+def _set_s16(model, value, ws_min=None):
+    eng = model._engine
+    assert eng.lib.kp2d_set_option(eng.handle, b"s16_min_items", value) == 0
+    if ws_min is not None:
+        assert eng.lib.kp2d_set_option(eng.handle, b"ws_min_tiles", ws_min) == 0
+
+
+@pytest.mark.parametrize("config,v3,ncls,B,H,W", [
+    # the conv2a map (H/2 x W/2) in 16 x 32 tiles: 52 x 88 = ragged rows (3.25 tiles) AND columns (2.75), 60 items on a
+    # 56-workgroup grid (n_my = 1 | 2); 120 x 160 = 8 x 5 tiles with the half-empty last tile row; 32 x 48 = 2 x 2 tiles
+    # with a half-empty column block; one frame = tiny grids, n_my = 1 everywhere
+    ("S", False, 28, 5, 104, 176),
+    ("S", True, 19, 3, 104, 176),
+    ("S", False, 28, 3, 240, 320),
+    ("S", False, 28, 1, 240, 320),
+    ("S", False, 28, 9, 64, 96),
+    ("S_A", True, 19, 2, 96, 128),
+])
+def test_split_activation_backbone_stage_equals_the_fp32_activation_path(config, v3, ncls, B, H, W):
+    """conv1b -> conv2a -> conv2b -> conv3a -> conv3b with the four inner tensors kept as the fp16 halves of the split
+    (S16P, kp2d_kernels.h; conv3x3_s16.hip reads them by LDS-DMA, the conv1b form and conv3x3_s16.hip write them), forced
+    by s16_min_items = 1 / ws_min_tiles = 1, against the same forward with fp32 NHWC activations (s16_min_items = -1):
+    a consumer multiplies the very halves its own staging would have split off, so EVERY output must be bit-identical; the
+    profile must say the forms ran; and the taps of the split tensors (hi + lo) must equal the fp32 activations to two
+    units in the last place."""
+    model, _ = product_model(config, v3, ncls)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=33)).to(DEV)
+    taps = ["backbone.conv1b", "backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"]
+    with torch.no_grad():
+        model(x[:1])
+        _set_s16(model, -1, 1)
+        ran_off = _kernels_that_ran(model, x)
+        ref = {k: v.clone() for k, v in model(x).items()}
+        ref_taps = {t: model.forward_with_tap(x, t, (B, 64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
+        _set_s16(model, 1, 1)
+        ran_on = _kernels_that_ran(model, x)
+        got = {k: v.clone() for k, v in model(x).items()}
+        got_taps = {t: model.forward_with_tap(x, t, (B, 64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
+        _set_s16(model, 0, 0)
+    assert not any("s16" in k for ks in ran_off.values() for k in ks), ran_off
+    assert any("<ws>s16" in k for k in ran_on["backbone.conv1b"]), ran_on["backbone.conv1b"]
+    for layer in ("backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"):
+        assert any("<s16>" in k for k in ran_on[layer]), (layer, ran_on[layer])
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()))
+    for t in taps:
+        r, g = ref_taps[t], got_taps[t]
+        assert r.shape == g.shape
+        if t.endswith("3b"):
+            assert torch.equal(r, g), t                      # conv3b stores fp32 either way
+        else:
+            # hi + lo against x: two units in the last place, and the fp16 subnormal floor for values below ~1e-4
+            assert bool(((r - g).abs() <= 3e-7 * r.abs() + 1.2e-7).all()), (t, float((r - g).abs().max()))
+
+
 @pytest.mark.parametrize("precision,form", [("f16x3", "auto"), ("f16x3", "general"), ("fp32", "auto")])
 def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(precision, form):
     """The fast tile forms need big launches (ws >= 1024 tiles, wsm >= 256 items, <1,2,16> >= 1024 wide tiles, flat32 >= 512)
@@ -1106,20 +1161,29 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
             model(x[:1])
         # automatic: two stream lanes of 32 frames, half the chip (128 workgroups) per launch, 128 items at 30 x 40
         _set_wsm(model, 0 if form == "auto" else -1)
+        _set_s16(model, 0 if form == "auto" else -1)
         ran = _kernels_that_ran(model, x)
         forms = {k for ks in ran.values() for k in ks}
         assert any("<ws>" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
         big = ("backbone.conv3b", "backbone.conv4a", "desc_head.confAa", "desc_head.convB", "seg_head.convs.1", "seg_head.convs.3", "seg_head.convs.7")
         for layer in big:
             # (automatic policy: 30 x 40 maps are one item per workgroup, conv3b has two chunks per item — both stay general)
-            if form == "auto" and layer not in ("seg_head.convs.3", "backbone.conv3b"):
+            if form == "auto" and layer == "backbone.conv3b":
+                continue                                     # (conv3x3_s16.hip: asserted below)
+            if form == "auto" and layer != "seg_head.convs.3":
                 assert any("<wsm>" in k for k in ran[layer]), (layer, ran[layer])
                 assert not any("<wsm>t" in k for k in ran[layer]), (layer, ran[layer])      # (the transposed walk is opt-in)
             else:
                 assert any("<2,1,16>" in k or "<2,1,8>" in k for k in ran[layer]), (layer, ran[layer])
         assert any("flat32" in k for k in forms), forms
-        # the 32-channel layers stay on the wide LDS-DMA tiles (32-channel items of the persistent form measured slower)
-        assert any("<1,2,16>" in k for k in ran["backbone.conv2a"]), ran["backbone.conv2a"]
+        # the 32-channel stage: split activations + LDS-DMA staging (conv3x3_s16.hip); with that form off, the wide tiles
+        # (32-channel items of the register-staging persistent form measured slower)
+        if form == "auto":
+            assert any("<ws>s16" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
+            for layer in ("backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"):
+                assert any("<s16>" in k for k in ran[layer]), (layer, ran[layer])
+        else:
+            assert any("<1,2,16>" in k for k in ran["backbone.conv2a"]), ran["backbone.conv2a"]
     with torch.no_grad():
         out = model(x)
         fwd = {b: {k: v[b:b + 1].cpu().numpy() for k, v in out.items()} for b in (0, 1, 30, 63)}      # (post_processing works in place)
