@@ -165,6 +165,38 @@ def cpu_baseline(args, sd_np):
                       f"forward+post+select, best of B in (1,8) = B{best_b}; " + "; ".join(log) + f"; cpu: {model_name}"}
 
 
+def rocprof_conv_frac(flops_per_forward, peak_tflops):
+    """The conv family's roofline fraction recomputed from the newest committed rocprofv3 --stats summary of this workload
+    (profiles/r<round>_kernel_stats_single_lane.csv: `KP2D_LANES=1 ... bench.py --in-flight 1` under the profiler, one lane,
+    nothing overlapped): sum of the conv3x3_f16x3* kernels' durations / forwards in that run (conv1a runs once per forward).
+    Printed beside the HIP-event figure so that the line and the CSV cannot drift apart unnoticed."""
+    import csv
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_single_lane.csv")):
+        m = re.match(r"r(\d+)_kernel_stats_single_lane\.csv$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None
+    conv_ns, fwd, launches = 0.0, 0, 0
+    for row in csv.DictReader(open(best[1])):
+        name = row["Name"]
+        if "conv3x3_f16x3" in name:
+            conv_ns += float(row["TotalDurationNs"])
+            launches += int(row["Calls"])
+        if "conv1a" in name:
+            fwd += int(row["Calls"])
+    if not fwd or not conv_ns:
+        return None
+    ms = conv_ns / fwd * 1e-6
+    rel = os.path.relpath(best[1], ROOT)
+    return {"file": rel, "git": file_commit(rel), "forwards": fwd, "conv_launches_per_forward": launches // fwd,
+            "conv_ms_per_forward": round(ms, 4), "achieved": round(flops_per_forward / (ms * 1e-3) / 1e12, 2),
+            "frac": round(flops_per_forward / (ms * 1e-3) / 1e12 / peak_tflops, 4)}
+
+
 def newest_traffic_file():
     """profiles/r<round>_traffic.json of the highest round (None if there is none)."""
     import glob
@@ -452,6 +484,10 @@ def main():
                 roof["traffic_unit"] = (f"bytes per launch; not measured in this run: PMC FETCH_SIZE x2 + WRITE_SIZE from {rel} "
                                         f"(git {tr.get('source_commit') or file_commit(rel)}), collected by tools/pmc_collect.sh on this workload")
                 roof["algorithmic_bytes_per_launch"] = round(a["bytes"] / a["launches"])
+            if B == 64 and (H, W) == (240, 320) and split and args.config == "S" and not args.v3:
+                rp = rocprof_conv_frac(a["flops"] / args.profile_steps, peak)
+                if rp:
+                    roof["rocprof"] = rp      # (not measured in this run: the committed profiler summary of the same command)
         except (OSError, KeyError, ValueError, TypeError):
             pass
         lb = LAYER_BOUNDARY_MB.get((H, W))

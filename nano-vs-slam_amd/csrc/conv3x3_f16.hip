@@ -361,6 +361,7 @@ constexpr int WS_IMG = 2 * WS_LO;                      // one input image (41,47
 constexpr int WS_N = 32, WS_WL = 9 * WS_N * 32;        // channels; byte offset of the wl plane behind the wh plane
 constexpr int WS_W = 2 * WS_IMG;                       // weight planes behind the two images
 constexpr int WS_LDS = WS_W + 2 * WS_WL;               // 101,376 B
+constexpr int WS_BLK = 2048;                           // S16P output: a wave's 16 pooled pixels x 32 channels x (hi, lo) on their way out
 constexpr int WS_G = WS_ROWS * WS_COLS * 4;            // 16-byte granules of a halo tile (2448)
 constexpr int WS_IT = (WS_G + 255) / 256;              // per staging thread (10)
 // trips of BOTH role loops of a workgroup that walks tiles t0, t0 + G, ... two per trip (the barrier contract below)
@@ -368,12 +369,13 @@ constexpr int WS_BARRIERS_PER_TRIP = 2;
 __host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (ntiles - t0 + 2 * G - 1) / (2 * G); }
 }  // namespace
 
-// S16OUT: the pooled output leaves as an S16P tensor (kp2d_kernels.h; its consumer is conv3x3_s16.hip).  The products are
-// then TRANSPOSED (weights = A operand, pixels = B, as conv3x3_wsm.hip): a lane's four accumulator registers are four
-// channels of ONE pixel, the 2 x 2 pooling block is lanes 4 q .. 4 q + 3 (DPP quad maximum), and with the two N-tiles' weight
-// rows interleaved in LDS (N-tile n, row 4 g + i = channel 8 g + 4 n + i) lane group g holds channels 8 g .. 8 g + 7 of its
-// pixel: [8 hi halves] / [8 lo halves] = two 16-byte stores from lane 4 q.  Same products in the same order: the values
-// that are split are bit-identical to those the fp32 form stores.
+// S16OUT: the pooled output leaves as an S16P tensor (kp2d_kernels.h; its consumer is conv3x3_s16.hip).  Same products, same
+// pooling; the pooled value of a lane (one channel of one pooled pixel per accumulator tile) is split there and the halves
+// go through a 2-KB wave-private LDS block laid out in the OUTPUT's order, so a wave's 16 pooled pixels x 32 channels leave
+// as TWO 16-byte stores per lane — four contiguous 256-byte row segments each — instead of eight 4-byte stores.
+// (First form of this epilogue: transposed products, a DPP quad maximum and the two N-tiles' weight rows interleaved so that a
+// lane held 8 channels of a pixel — 240 vector instructions per tile and stores from a quarter of the lanes: 0.150 ms against
+// 0.134 for the fp32 output, the layer became bound by vector issue.)
 template <bool S16OUT>
 __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -386,12 +388,9 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   constexpr int OOB = 0x7ffffff0;
 
   // weights: the chunk's [slot][n][16 hi | 16 lo] rows -> [wh plane | wl plane] (as the kernel above), once
-  for (int gi = tid; gi < 9 * WS_N * 4; gi += 768) {
-    const int row = gi >> 2, n = row & (WS_N - 1);
-    const int rp = S16OUT ? (row - n) + 16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3) : row;
-    *reinterpret_cast<float4*>(sm + WS_W + rp * 32 + (gi & 1) * 16 + ((gi >> 1) & 1) * WS_WL) =
+  for (int gi = tid; gi < 9 * WS_N * 4; gi += 768)
+    *reinterpret_cast<float4*>(sm + WS_W + (gi >> 2) * 32 + (gi & 1) * 16 + ((gi >> 1) & 1) * WS_WL) =
         reinterpret_cast<const float4*>(a.w)[gi];
-  }
 
   // ---- producer state: granule gi = ptid + 256 it of a halo tile = (halo pixel gi / 4, channels 4 (gi % 4) ..) ----
   const int ptid = tid - 512;
@@ -450,14 +449,9 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   auto tap_off = [](int t) constexpr { return ((t / 3) * WS_PITCH + (t % 3)) * F_PXB; };
   const float slope = a.act == ACT_LEAKY ? 0.01f : (a.act == ACT_RELU ? 0.f : 1.f);
   const int Hp = H >> 1, Wp = W >> 1;
-  // fp32 form: lane = channel (n 16 + lp) of four pixels; S16P form: lane = pixel, channels 8 lg .. 8 lg + 7
-  constexpr int NSC = S16OUT ? 8 : NN;
-  float sc[NSC], sh[NSC];
+  float sc[NN], sh[NN];
 #pragma unroll
-  for (int n = 0; n < NSC; ++n) {
-    const int c = S16OUT ? 8 * lg + n : n * 16 + lp;
-    sc[n] = a.scale[c]; sh[n] = a.shift[c];
-  }
+  for (int n = 0; n < NN; ++n) { sc[n] = a.scale[n * 16 + lp]; sh[n] = a.shift[n * 16 + lp]; }
 
   auto multiply = [&](int t, int buf) {
     const int b = t / per_frame, r = t - b * per_frame;
@@ -490,84 +484,62 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
           const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            if constexpr (S16OUT) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], x, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], x, acc[m][n], 0, 0, 0);
-            } else {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
-            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bh[n], acc[m][n], 0, 0, 0);
           }
         } else {
           const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
           const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + WS_LO);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            if constexpr (S16OUT) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh, acc[m][n], 0, 0, 0);
-            } else {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
-            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, bh[n], acc[m][n], 0, 0, 0);
           }
         }
       }
     }
     if constexpr (S16OUT) {
-      // lane (lp, lg): pixel lp of M-tile m = (row (lp >> 1) & 1, column 2 (lp >> 2) + (lp & 1)), channels 8 lg + 4 n + r.
-      // Pooled pixel = the quad of lanes 4 q .. 4 q + 3; lane 4 q stores it (soffset = 0: the gfx950 store hazard,
-      // conv3x3_wsm.hip)
-      const int obs = Hp * Wp * a.cout;                // output frame stride, floats (S16P: the same bytes as fp32 NHWC)
-      const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(a.out1 + (size_t)b * obs, 0, obs * 4, 0x00020000);
-      const int cpart = (lg >> 1) * (Hp * 2 * Wp * 32) + (lg & 1) * 16;
-      const int cinv = (8 * lg < a.cout && (lp & 3) == 0) ? 0 : OOB;
+      // lane (lp, lg), tile (m, n): channel 16 n + lp of the pooled pixel (row m / 2, column 4 (m % 2) + lg) of this wave's 2 x 8
+      // pooled pixels.  LeakyReLU / ReLU is monotonic, so it is applied once, to the maximum (the same bits as the maximum of
+      // the four activations).  Block layout = the order the bytes leave in: piece e = ((n 2 + plane) 2 + row) 16 + 2 column
+      // + (lp >> 3) of 16 bytes, halves lp & 7 inside it.
+      char* const blk = sm + WS_LDS + wave8 * WS_BLK;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        float v[8];
+        float v[NN];
 #pragma unroll
-        for (int n = 0; n < NN; ++n)
+        for (int n = 0; n < NN; ++n) {
+          const float t0 = fmaf(acc[m][n][0], sc[n], sh[n]), t1 = fmaf(acc[m][n][1], sc[n], sh[n]);
+          const float t2 = fmaf(acc[m][n][2], sc[n], sh[n]), t3 = fmaf(acc[m][n][3], sc[n], sh[n]);
+          const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+          v[n] = fmaxf(tm, tm * slope);
+        }
+        f16x2 hi, lo;
+        split2(v[0], v[1], hi, lo);                    // (element n of hi / lo = the halves of N-tile n's value)
+        const int e0 = ((m / CB) * 16 + (4 * (m % CB) + lg) * 2 + (lp >> 3)) * 16 + (lp & 7) * 2;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float tt = fmaf(acc[m][n][r], sc[4 * n + r], sh[4 * n + r]);
-            v[4 * n + r] = fmaxf(tt, tt * slope);
-          }
-        float p[8];
-        asm("s_nop 1\n\t"
-            "v_max_f32_dpp %0, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %1, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %2, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %3, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %4, %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %5, %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %6, %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %7, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_max_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1"
-            : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
-            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-        f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
-        split2(p[0], p[1], h0, l0);
-        split2(p[2], p[3], h1, l1);
-        split2(p[4], p[5], h2, l2);
-        split2(p[6], p[7], h3, l3);
-        const i32x4 hi = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
-        const i32x4 lo = {__builtin_bit_cast(int, l0), __builtin_bit_cast(int, l1), __builtin_bit_cast(int, l2), __builtin_bit_cast(int, l3)};
-        const int yp = (y0 + wr * 4 + 2 * (m / CB)) >> 1, xp = ((x0 + 16 * ph + 8 * (m % CB)) >> 1) + (lp >> 2);
-        const int inv = ((yp < Hp && xp < Wp) ? 0 : OOB) | cinv;
-        const int o = (yp * 2 * Wp + xp) * 32 + cpart;
-        __builtin_amdgcn_raw_buffer_store_b128(hi, rso, o | inv, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lo, rso, (o + Wp * 32) | inv, 0, 0);
+        for (int n = 0; n < NN; ++n) {
+          *reinterpret_cast<_Float16*>(blk + e0 + (n * 2 + 0) * 512) = hi[n];
+          *reinterpret_cast<_Float16*>(blk + e0 + (n * 2 + 1) * 512) = lo[n];
+        }
       }
+      // (the halves were written as fp16 lvalues and are read back as 16-byte vectors: a compiler fence keeps the reads behind the
+      // writes — the LDS itself executes a wave's instructions in order — and a second one keeps the next tile's writes behind these reads)
+      asm volatile("" ::: "memory");
+      // lane L, chunk n: piece e = L + 64 n -> half L & 1, column (L >> 1) & 7, row (L >> 4) & 1, plane L >> 5
+      const int obs = Hp * Wp * a.cout;                // output frame stride, floats (S16P: the same bytes as fp32 NHWC)
+      const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(a.out1 + (size_t)b * obs, 0, obs * 4, 0x00020000);
+      const int yp = ((y0 + wr * 4) >> 1) + ((lane >> 4) & 1), xp = ((x0 + 16 * ph) >> 1) + ((lane >> 1) & 7);
+      const int inv = (yp < Hp && xp < Wp) ? 0 : OOB;
+      const int o = ((yp * 2 + (lane >> 5)) * Wp + xp) * 32 + (lane & 1) * 16;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const i32x4 pc = *reinterpret_cast<const i32x4*>(blk + (lane + 64 * n) * 16);
+        // (soffset = 0: the gfx950 store hazard, conv3x3_wsm.hip)
+        __builtin_amdgcn_raw_buffer_store_b128(pc, rso, (o + n * (Hp * 2 * Wp * 32)) | inv | (16 * n < a.cout ? 0 : OOB), 0, 0);
+      }
+      asm volatile("" ::: "memory");
       return;
     }
     // pooled epilogue (conv_epilogue.inc, ST_NHWC_POOL): the four registers of a lane are one 2 x 2 pixel block
@@ -655,7 +627,7 @@ static int launch_ws(const ConvArgs& a0, hipStream_t s) {
     return n > 0 ? n : 256;
   }();
   const int grid = (int)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel<S16OUT>, dim3(grid), dim3(768), WS_LDS, s, a, (int)ntiles);
+  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel<S16OUT>, dim3(grid), dim3(768), WS_LDS + (S16OUT ? 8 * WS_BLK : 0), s, a, (int)ntiles);
   return (int)hipGetLastError();
 }
 

@@ -1119,11 +1119,11 @@ def test_split_activation_backbone_stage_equals_the_fp32_activation_path(config,
         _set_s16(model, -1, 1)
         ran_off = _kernels_that_ran(model, x)
         ref = {k: v.clone() for k, v in model(x).items()}
-        ref_taps = {t: model.forward_with_tap(x, t, (B, 64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
+        ref_taps = {t: model.forward_with_tap(x, t, (64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
         _set_s16(model, 1, 1)
         ran_on = _kernels_that_ran(model, x)
         got = {k: v.clone() for k, v in model(x).items()}
-        got_taps = {t: model.forward_with_tap(x, t, (B, 64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
+        got_taps = {t: model.forward_with_tap(x, t, (64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
         _set_s16(model, 0, 0)
     assert not any("s16" in k for ks in ran_off.values() for k in ks), ran_off
     assert any("<ws>s16" in k for k in ran_on["backbone.conv1b"]), ran_on["backbone.conv1b"]
