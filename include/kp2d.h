@@ -192,6 +192,24 @@ int kp2d_match_descriptors_ex(const float* d0, const int32_t* n0, const float* d
 int kp2d_match_pairs(const int32_t* match_q, const float* match_d, const float* pts0, const float* pts1, int B, int max0,
                      int max1, float* pairs, int32_t* idx, float* dist, int32_t* count, void* stream);
 
+/* The VO loop's top_k_matches cap on the device, fused with the compaction above (replaces
+ * src/visual_odometry/visual_odometry.py:272-283 — BF branch: np.argpartition(score, k)[:k], the k SMALLEST distances —
+ * and :26-32 + :260-266 — LightGlue branch: get_matches_scores(...) then scores.topk(k), the k LARGEST matching scores):
+ *   mode KP2D_TOPK_BF: match_q [B,max1] + val = match_d [B,max1] (kp2d_match_descriptors); pair = (pts0[match_q[t]], pts1[t])
+ *   mode KP2D_TOPK_LG: matches0 [B,max0] int64 + val = matching_scores0 [B,max0] (kp2d_lg_forward);
+ *                      pair = (pts0[q], pts1[matches0[q]])
+ *   k <= 0: every match.  At most kcap = min(k, n) pairs per frame pair (n = max1 / max0), BEST FIRST, equal values by lower
+ *   source row (the reference's order within its k survivors is unspecified; callers use the set).
+ *   pairs [B,kcap,4] (x0, y0, x1, y1), idx [B,kcap,2] (row in set 0, row in set 1; -1 past count), out_val [B,kcap]
+ *   (distance / score), count [B]; pairs / idx / out_val may each be NULL.
+ *   scratch: kp2d_match_topk_scratch_bytes(B, max0, max1) bytes of device memory. */
+#define KP2D_TOPK_BF 0
+#define KP2D_TOPK_LG 1
+size_t kp2d_match_topk_scratch_bytes(int B, int max0, int max1);
+int kp2d_match_topk_pairs(int mode, const int32_t* match_q, const int64_t* matches0, const float* val, const float* pts0,
+                          const float* pts1, int B, int max0, int max1, int k, float* pairs, int32_t* idx, float* out_val,
+                          int32_t* count, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* when on, every kernel launch of kp2d_forward is bracketed by HIP events on the caller's stream */
 int kp2d_set_profiling(kp2d_model* m, int on);

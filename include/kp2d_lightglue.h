@@ -58,6 +58,19 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
                     float* log_assignment, int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
                     float* ref_desc0, float* ref_desc1, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same on PADDED keypoint sets: n0 / n1 [B] int32 device arrays say how many rows of kpts0 / desc0 (kpts1 / desc1) exist,
+ * the remaining rows of the M / N are padding.  This is what lets the matcher sit inside a replayed HIP graph behind a
+ * threshold + top-k selection whose count changes from frame to frame (the reference hands LightGlue exactly the selected
+ * rows, src/visual_odometry/visual_odometry.py:198-258: a different tensor shape every frame).  Padding rows are no keys in
+ * any attention, carry no assignment mass, and come out as matches = -1 / scores = 0; the valid rows' results are those of
+ * kp2d_lg_forward on the n0 / n1 rows alone (up to fp32 summation order).  log_assignment entries of padding rows / columns
+ * are -inf (inner block) or unspecified (border).  size0 / size1 are required (the default would look at every row). */
+int kp2d_lg_forward_counts(kp2d_lg* m, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                           const float* size0, const float* size1, const int32_t* n0, const int32_t* n1, int B, int M, int N,
+                           float filter_threshold, float* log_assignment, int64_t* matches0, int64_t* matches1,
+                           float* mscores0, float* mscores1, float* ref_desc0, float* ref_desc1, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

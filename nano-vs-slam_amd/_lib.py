@@ -92,6 +92,9 @@ SIGNATURES = {
     "kp2d_match_descriptors_ex": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_uint32,
                                             _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kp2d_match_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "kp2d_match_topk_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "kp2d_match_topk_pairs": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
+                                        C.c_size_t, _P]),
     "kp2d_set_profiling": (C.c_int, [_P, C.c_int]),
     "kp2d_profile_count": (C.c_int, [_P]),
     "kp2d_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _F,
@@ -111,6 +114,7 @@ SIGNATURES = {
     "kp2d_lg_finalize_weights": (C.c_int, [_P]),
     "kp2d_lg_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     "kp2d_lg_forward": (C.c_int, [_P] + [_P] * 6 + [C.c_int] * 3 + [C.c_float] + [_P] * 7 + [_P, C.c_size_t, _P]),
+    "kp2d_lg_forward_counts": (C.c_int, [_P] + [_P] * 8 + [C.c_int] * 3 + [C.c_float] + [_P] * 7 + [_P, C.c_size_t, _P]),
 }
 
 _lib = None

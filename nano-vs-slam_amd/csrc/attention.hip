@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
+  const int C = a.C, d = C / a.heads, S = a.S, TS = a.T;      // TS: rows per sequence in memory
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const int T = a.tcount ? min(TS, a.tcount[bk]) : TS;         // keys that exist (LightGlue on padded keypoint sets)
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qi = q0 + j;
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
@@ -231,8 +233,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
   for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
-  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + h * d;
+  const float* kvb = a.kv + (size_t)bk * TS * kvs + a.k_off + h * d;
 
   for (int kc = 0; kc < T; kc += AKT) {
     __syncthreads();
@@ -507,7 +508,9 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
   } else {
     hd = blockIdx.y; b = blockIdx.z; qblk = blockIdx.x;
   }
-  const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
+  const int C = a.C, d = C / a.heads, S = a.S, TS = a.T;
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const int T = a.tcount ? min(TS, a.tcount[bk]) : TS;
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
   const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
   const int qi = qblk * (NTHR / 2) + wave * 32 + i;
@@ -533,8 +536,7 @@ __global__ __launch_bounds__(NTHR, WPS) void attention_split_kernel(const AttnAr
     *reinterpret_cast<h16x8*>(&Vs[row * SVP + 16 + 32 * (part >> 1) + 8 * (part & 1)]) = c;
   }
   const _Float16* const vph = &Vs[(4 * h + ((lane & 15) >> 2)) * SVP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
-  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
-  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
+  const float* kvb = a.kv + (size_t)bk * TS * kvs + a.k_off + hd * d;
 
   for (int kc = 0; kc < T; kc += SKT) {
     __syncthreads();
@@ -578,7 +580,9 @@ __global__ __launch_bounds__(256, 4) void attention_ksplit_kernel(const AttnArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int C = a.C, d = C / a.heads, S = a.S, T = a.T;
+  const int C = a.C, d = C / a.heads, S = a.S, TS = a.T;
+  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
+  const int T = a.tcount ? min(TS, a.tcount[bk]) : TS;
   const int qs = a.q_stride ? a.q_stride : C, kvs = a.kv_stride ? a.kv_stride : 2 * C;
   const int vd = (a.v_off ? a.v_off : C) - a.k_off, os = a.out_stride ? a.out_stride : C;
   const int qi = blockIdx.x * 32 + i;
@@ -598,8 +602,7 @@ __global__ __launch_bounds__(256, 4) void attention_ksplit_kernel(const AttnArgs
     *reinterpret_cast<h16x8*>(&Vw[row * SVP + 16 + 32 * (pt >> 1) + 8 * (pt & 1)]) = c;
   }
   const _Float16* const vph = &Vw[(4 * h + ((lane & 15) >> 2)) * SVP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
-  const int bk = a.kv_bshift ? (b + a.kv_bshift) % a.B : b;
-  const float* kvb = a.kv + (size_t)bk * T * kvs + a.k_off + hd * d;
+  const float* kvb = a.kv + (size_t)bk * TS * kvs + a.k_off + hd * d;
   const int Tw = ((T + 127) >> 7) << 5;                  // keys per wave, a multiple of the 32-key tile
   const int k0 = wave * Tw, k1 = min(T, k0 + Tw);
   // granule (key, 4 channels) of a round: lane -> key lane / 4 (+ 16), channels 4 (lane % 4)

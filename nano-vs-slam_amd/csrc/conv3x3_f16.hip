@@ -62,8 +62,10 @@ __host__ __device__ constexpr int slot_tap(int s) { return s == 2 ? 3 : s == 3 ?
 // FLAT32: the 256-thread form on 8 x 32 pixel tiles (a wave owns two rows x 32 columns = four M-tiles, as on 16 x 16) for
 //     the planar-output 32-channel layers on maps with a half-empty last 16-row tile row: no ragged row, and every row
 //     of a channel plane a workgroup writes is a whole 128-byte line.
-template <int NH, int NP, int TH, bool FLAT32 = false>
-__global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
+// (the body as a device function of (arguments, workgroup index, workgroups, channel group): conv3x3_f16x3_kernel below runs it
+// on its own grid, conv3x3_f16x3_multi_kernel runs several independent layers' grids as one launch)
+template <int NH, int NP, int TH, bool FLAT32>
+__device__ __forceinline__ void conv3x3_f16x3_body(const ConvArgs& a, const int wg_x, const int wg_nx, const int wg_y) {
   static_assert(NH * NP <= 2, "one workgroup is 256 or 512 threads");
   static_assert(TH == 16 || (TH == 8 && NP == 1), "8-row tiles: the 256-thread form (16 wide) and the 64-channel form (32 wide)");
   static_assert(!FLAT32 || (NH == 1 && NP == 1 && TH == 8), "the flat 32-wide form is a 256-thread form");
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   // the ragged last tile row of a map (below) the waves that still have work are then spread over all four SIMDs.
   const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 2 * half) & 3);
   // XCD-aware tile order (conv3x3.hip): every XCD gets a contiguous run of tiles
-  int bid = blockIdx.x;
+  int bid = wg_x;
   {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    const int nblk = wg_nx, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
   const int tx = bid % a.tiles_x;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   const int b = bid / a.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW;
   const int H = a.H, W = a.W;
-  const int n0 = blockIdx.y * N;
+  const int n0 = wg_y * N;
   // Ragged last tile row (map height not a multiple of 16: 120 -> 8 valid rows, 60 -> 12, 30 -> 14): a wave whose
   // four rows lie wholly below the map multiplies and stores nothing (it still stages and joins every barrier).
   // H = 120 / 60 otherwise spend 6.25 % of their matrix work on padding rows.
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(src1), 0, (int)((a.in1.bs - a.in1.o) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w + (size_t)blockIdx.y * nchunk * 9 * N * KC), 0, nchunk * 9 * N * KC * 4, 0x00020000);
+      const_cast<float*>(a.w + (size_t)wg_y * nchunk * 9 * N * KC), 0, nchunk * 9 * N * KC * 4, 0x00020000);
   const bool uniform = ((c0 | a.cin) & (KC - 1)) == 0;
 
   auto prefetch_in = [&](int ch) {
@@ -344,6 +346,23 @@ __global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f
 #undef EPI_TH
 }
 
+template <int NH, int NP, int TH, bool FLAT32 = false>
+__global__ __launch_bounds__(256 * NH * NP, NH * NP == 1 ? 3 : 4) void conv3x3_f16x3_kernel(const ConvArgs a) {
+  conv3x3_f16x3_body<NH, NP, TH, FLAT32>(a, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Up to four INDEPENDENT layers as one launch (blockIdx.z = layer; a workgroup beyond its layer's grid leaves at once).  A single
+// frame's forward is a chain of ~25 dependent launches, each as long as ONE workgroup's serial chain (8-10 us whatever it
+// computes): layers of different heads that wait for the same predecessor cost one such latency together instead of one each
+// (kp2d_api.cpp groups them on small grids).  Same code per layer as its own launch: bit-identical.
+struct ConvMultiArgs { ConvArgs a[4]; int n; };
+__global__ __launch_bounds__(256, 3) void conv3x3_f16x3_multi_kernel(const ConvMultiArgs m) {
+  const ConvArgs& a = m.a[blockIdx.z];
+  const int nx = a.tiles_x * a.tiles_y * a.B;
+  if ((int)blockIdx.x >= nx || (int)blockIdx.y >= a.npad / 32) return;
+  conv3x3_f16x3_body<1, 1, 8, false>(a, blockIdx.x, nx, blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Single-chunk layers (conv1b: 16 -> 32 channels at full resolution, max-pooled output): warp-specialised and persistent.
 // With one chunk a workgroup of the kernel above is load -> commit -> multiply -> store with nothing of its own to overlap,
@@ -376,8 +395,35 @@ __host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (
 // (First form of this epilogue: transposed products, a DPP quad maximum and the two N-tiles' weight rows interleaved so that a
 // lane held 8 channels of a pixel — 240 vector instructions per tile and stores from a quarter of the lanes: 0.150 ms against
 // 0.134 for the fp32 output, the layer became bound by vector issue.)
-template <bool S16OUT>
-__global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const int ntiles) {
+// STEM: the staging waves do not read backbone.conv1a's output, they COMPUTE it — conv1a (3 -> 16 channels, 27 taps, BatchNorm,
+// LeakyReLU: modules/encoders.py:20-29, 108) for the tile's 18 x 34 halo pixels straight from the RGB planes, on the matrix
+// cores, split and written into conv1b's operand image.  conv1a's launch and the 315 MB (64 frames) it writes and conv1b reads
+// back — the largest tensor of the forward after `skip` — disappear.  Two VALU forms of this fusion lost in round 3
+// (profiles/r3_ab_warp_specialised.txt: 529 kFLOP of fp32 FMAs per tile are more cycles of the CU's whole vector ALU than
+// conv1b's matrix work).  Here a staging wave owns a band of 4-5 halo rows: it keeps the band's RGB window (band + 2 rows x 40
+// columns) as fp16 hi / lo planes in a wave-private LDS block laid out [row][x][c0 c1 c2 0] — 8 bytes per pixel, so a lane's
+// B operand of v_mfma_f32_16x16x32_f16 (K = 8 taps x 4 channels: two taps per k-group) is two aligned ds_read_b64 — and
+// runs 11 M-tiles of 16 halo pixels x 16 channels: six MFMAs each (8 taps + the ninth, times the three split terms).
+// No barrier beyond the tile's own: the window is wave-private and a wave's LDS instructions execute in order.
+// Arithmetic: split-fp16 products like every other layer of this precision mode (x = xh + xl, w 2^e = wh + wl, fp32
+// accumulate: ~1e-7 relative to the exact fp32 FMA chain of conv1a_kernel) — NOT the bits of the stand-alone conv1a launch,
+// which small grids keep: results of a forward are bit-identical within a schedule (lane count, steps in flight), and agree
+// to fp32 rounding between the fused and the unfused first layer (kp2d_set_option("stem_fusion", 0) turns it off).
+struct StemArgs {
+  const float* x;                     // [B,3,H,W] frames
+  const float* w;                     // conv1a weights [27][16] (k = ci 9 + dy 3 + dx)
+  const float* scale; const float* shift;   // BatchNorm folded, [16]
+  float wscale, wunscale;             // 2^e, 2^-e: the weights are split as w 2^e (lo halves stay normal)
+  int act;
+};
+namespace {
+constexpr int ST_XR = 7, ST_XC = 40;                   // window rows (a 5-row band + 2) and columns (x0 - 4 .. x0 + 35)
+constexpr int ST_XPL = ST_XR * ST_XC * 8;              // one plane of a wave's window (2,240 B)
+constexpr int ST_MT = 11;                              // M-tiles of 16 halo pixels per band (5 rows x 34 = 170 pixels)
+}  // namespace
+
+template <bool S16OUT, bool STEM>
+__global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs a, const StemArgs st, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
@@ -432,6 +478,136 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
       *reinterpret_cast<f16x4*>(sm + WS_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
     }
+  };
+
+  // ---- STEM producer state (see the kernel comment) ----
+  const int pw = wave8 - 8;                                                        // staging wave 0..3
+  const int band0 = pw < 2 ? 5 * pw : 10 + 4 * (pw - 2), band_n = pw < 2 ? 5 : 4;  // halo rows [band0, band0 + band_n)
+  const int band_px = band_n * WS_COLS;
+  char* const xw = sm + WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (pw & 3) * 2 * ST_XPL;   // this wave's window: hi plane | lo plane
+  float4 rx[STEM ? 2 : 1][STEM ? 4 : 1];
+  int tset[2] = {0, 0};                                                            // tile carried by each register set
+  f16x8 swh[2], swl[2];                                                            // A operands: taps (2 lg, 2 lg + 1) and tap 8
+  float ssc[4], ssh[4];
+  int sbase[STEM ? ST_MT : 1];
+  int so0 = 0, so1 = 0;
+  const int slg = lane >> 4, slp = lane & 15;
+  if constexpr (STEM) {
+    if (!consumer) {
+      for (int e = lane; e < 2 * ST_XPL / 16; e += 64) *reinterpret_cast<float4*>(xw + 16 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      // weights of output channel slp: k-group slg holds taps 2 slg, 2 slg + 1 (MFMA 0) / tap 8 in k-group 0 (MFMA 1), 4 halves per
+      // tap = channels (0, 1, 2, padding)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+          const int tap = j == 0 ? 2 * slg + (hh >> 2) : 8, ci = hh & 3;
+          const bool on = ci < 3 && (j == 0 || (slg == 0 && hh < 4));
+          const float wv = on ? st.w[(ci * 9 + tap) * 16 + slp] * st.wscale : 0.f;
+          const _Float16 h = (_Float16)wv;
+          swh[j][hh] = h;
+          swl[j][hh] = (_Float16)(wv - (float)h);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ssc[i] = st.scale[4 * slg + i] * st.wunscale; ssh[i] = st.shift[4 * slg + i]; }
+      auto toff = [](int t) { return ((t / 3) * ST_XC + (t % 3)) * 8; };
+      so0 = toff(2 * slg);
+      so1 = toff(2 * slg + 1);
+#pragma unroll
+      for (int mt = 0; mt < ST_MT; ++mt) {
+        int p = 16 * mt + slp;
+        p = p < band_px ? p : band_px - 1;
+        const int r = p / WS_COLS, c = p - r * WS_COLS;
+        sbase[mt] = (r * ST_XC + c + 2) * 8;            // window pixel of tap (0, 0): row r, column c + 2 (halo column c = x0 - 1 + c)
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(STEM ? st.x : a.in0.p), 0, STEM ? (int)((long)a.B * 3 * H * W * 4) : 0, 0x00020000);
+  // loads of tile t's window: slot e = lane + 64 j -> window row e / 30, plane (e % 30) / 10, four columns 4 (e % 10) ..
+  auto stem_request = [&](int t, auto set_c) {
+    constexpr int RS = decltype(set_c)::value;
+    tset[RS] = t;
+    const bool live = t < ntiles;
+    const int b = t / per_frame, r = t - b * per_frame;
+    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    const int gy0 = ty * WS_TH - 2 + band0, gx0 = tx * WS_TW - 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j, wr = e / 30, rem = e - 30 * wr, c = rem / 10, q = rem - 10 * c;
+      const int gy = gy0 + wr, gx = gx0 + 4 * q;
+      const bool ok = live && wr < band_n + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
+      const int off = ok ? (((b * 3 + c) * H + gy) * W + gx) * 4 : OOB;
+      rx[STEM ? RS : 0][STEM ? j : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+    }
+  };
+  auto stem_commit = [&](int buf, auto set_c) {
+    constexpr int RS = decltype(set_c)::value;
+    // window: fp32 -> hi / lo halves at [row][x][c]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j, wr = e / 30, rem = e - 30 * wr, c = rem / 10, q = rem - 10 * c;
+      if (wr >= ST_XR) continue;
+      const float4 v = rx[STEM ? RS : 0][STEM ? j : 0];
+      f16x2 h0, l0, h1, l1;
+      split2(v.x, v.y, h0, l0);
+      split2(v.z, v.w, h1, l1);
+      char* const d = xw + (wr * ST_XC + 4 * q) * 8 + c * 2;
+      *reinterpret_cast<_Float16*>(d) = h0[0];
+      *reinterpret_cast<_Float16*>(d + 8) = h0[1];
+      *reinterpret_cast<_Float16*>(d + 16) = h1[0];
+      *reinterpret_cast<_Float16*>(d + 24) = h1[1];
+      *reinterpret_cast<_Float16*>(d + ST_XPL) = l0[0];
+      *reinterpret_cast<_Float16*>(d + ST_XPL + 8) = l0[1];
+      *reinterpret_cast<_Float16*>(d + ST_XPL + 16) = l1[0];
+      *reinterpret_cast<_Float16*>(d + ST_XPL + 24) = l1[1];
+    }
+    asm volatile("" ::: "memory");                     // (halves written as fp16 lvalues, read back as 8-byte vectors below)
+    const int t = tset[RS];
+    const int b = t / per_frame, r = t - b * per_frame;
+    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    const int y0 = ty * WS_TH - 1 + band0, x0 = tx * WS_TW - 1;      // map position of the band's first halo pixel
+    const float slope1 = st.act == ACT_LEAKY ? 0.01f : (st.act == ACT_RELU ? 0.f : 1.f);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int mt = 0; mt < ST_MT; ++mt) {
+      if (16 * mt >= band_px) break;                   // (the 4-row bands: 136 pixels = 9 M-tiles)
+      const char* const ph = xw + sbase[mt];
+      const h4 a0 = *reinterpret_cast<const h4*>(ph + so0), a1 = *reinterpret_cast<const h4*>(ph + so1);
+      const h4 b0 = *reinterpret_cast<const h4*>(ph + so0 + ST_XPL), b1 = *reinterpret_cast<const h4*>(ph + so1 + ST_XPL);
+      const h4 a8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8), b8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8 + ST_XPL);
+      const f16x8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const f16x8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const f16x8 yh = {a8[0], a8[1], a8[2], a8[3], 0, 0, 0, 0};
+      const f16x8 yl = {b8[0], b8[1], b8[2], b8[3], 0, 0, 0, 0};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc, 0, 0, 0);
+      // lane (slp, slg): halo pixel 16 mt + slp of the band, channels 4 slg .. 4 slg + 3
+      const int p = 16 * mt + slp;
+      const int pr = p / WS_COLS, pc = p - pr * WS_COLS;
+      const int y = y0 + pr, x = x0 + pc;
+      const bool in = p < band_px && y >= 0 && y < H && x >= 0 && x < W;      // outside the map: conv1b's zero padding
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float tt = fmaf(acc[i], ssc[i], ssh[i]);
+        v[i] = in ? fmaxf(tt, tt * slope1) : 0.f;
+      }
+      f16x2 h0, l0, h1, l1;
+      split2(v[0], v[1], h0, l0);
+      split2(v[2], v[3], h1, l1);
+      if (p < band_px) {
+        const int lb = buf * WS_IMG + ((band0 + pr) * WS_PITCH + pc) * F_PXB + slg * 8;
+        *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<f16x4*>(sm + WS_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+    }
+    asm volatile("" ::: "memory");
   };
 
   // ---- consumer state: wave (w, ph) owns tile rows 4 w .. 4 w + 3 x columns 16 ph .. + 15 = four M-tiles (2 x 8 pixels),
@@ -593,6 +769,22 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       __syncthreads();
       static_assert(WS_BARRIERS_PER_TRIP == 2, "multiplying loop: two barriers per trip");
     }
+  } else if constexpr (STEM) {
+    stem_request(t0, S0{});
+    stem_commit(0, S0{});
+    stem_request(t0 + G, S0{});
+    stem_request(t0 + 2 * G, S1{});
+    __syncthreads();
+    for (int k = 0; k < trips; ++k) {
+      const int t = t0 + 2 * k * G;
+      stem_commit(1, S0{});
+      stem_request(t + 3 * G, S0{});
+      __syncthreads();
+      stem_commit(0, S1{});
+      stem_request(t + 4 * G, S1{});
+      __syncthreads();
+      static_assert(WS_BARRIERS_PER_TRIP == 2, "staging loop (stem): two barriers per trip");
+    }
   } else {
     request(t0, S0{});
     commit(0, S0{});
@@ -612,14 +804,14 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   }
 }
 
-template <bool S16OUT>
-static int launch_ws(const ConvArgs& a0, hipStream_t s) {
+template <bool S16OUT, bool STEM>
+static int launch_ws_t(const ConvArgs& a0, const StemArgs& st, hipStream_t s) {
   ConvArgs a = a0;
   a.tiles_x = (a.W + WS_TW - 1) / WS_TW;
   a.tiles_y = (a.H + WS_TH - 1) / WS_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   static PerDeviceOnce lds_once;
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel<S16OUT>))) return e;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel<S16OUT, STEM>))) return e;
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -627,8 +819,17 @@ static int launch_ws(const ConvArgs& a0, hipStream_t s) {
     return n > 0 ? n : 256;
   }();
   const int grid = (int)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL(conv3x3_f16x3_ws_kernel<S16OUT>, dim3(grid), dim3(768), WS_LDS + (S16OUT ? 8 * WS_BLK : 0), s, a, (int)ntiles);
+  hipLaunchKernelGGL((conv3x3_f16x3_ws_kernel<S16OUT, STEM>), dim3(grid), dim3(768),
+                     WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (STEM ? 4 * 2 * ST_XPL : 0), s, a, st, (int)ntiles);
   return (int)hipGetLastError();
+}
+template <bool S16OUT>
+static int launch_ws(const ConvArgs& a, hipStream_t s) {
+  if (a.stem_x) {      // conv1a computed by the staging waves (kp2d_api.cpp hands its arguments over instead of launching it)
+    const StemArgs st{a.stem_x, a.stem_w, a.stem_scale, a.stem_shift, a.stem_wscale, 1.f / a.stem_wscale, a.stem_act};
+    return launch_ws_t<S16OUT, true>(a, st, s);
+  }
+  return launch_ws_t<S16OUT, false>(a, StemArgs{}, s);
 }
 
 // the map-side conditions of the warp-specialised conv1b form (the layer-side ones — 16 -> 32 channels, pooled — are the
@@ -664,6 +865,49 @@ static int launch_f(const ConvArgs& a0, hipStream_t s) {
 }
 
 namespace { thread_local const char* g_variant = ""; }
+
+static size_t f_lds_bytes(const ConvArgs& a, int N, int TW, int TH, int slabs) {
+  size_t lds = (size_t)f_w(TW, TH) + (size_t)slabs * 2 * 9 * N * 32;
+  const size_t lds_out = (size_t)N * (TH * TW + 4) * sizeof(float);
+  if (a.store == ST_NCHW && lds_out > lds) lds = lds_out;
+  const size_t lds_tile = (size_t)TH * TW * N * sizeof(float);
+  if (a.store != ST_NCHW && lds_tile > lds) lds = lds_tile;
+  return lds;
+}
+
+// n <= 4 independent layers, every one a layer the single-frame form <1,1,8> would take (32-channel groups, a grid below 256
+// workgroups); -1000: not all of them are — the caller then launches them one by one
+int launch_conv3x3_f16x3_multi(const ConvArgs* list, int n, hipStream_t s) {
+  if (n < 2 || n > 4) return -1000;
+  static const bool multi_on = !(getenv("KP2D_MULTI") && getenv("KP2D_MULTI")[0] == '0');      // (A/B knob)
+  if (!multi_on) return -1000;
+  ConvMultiArgs m{};
+  m.n = n;
+  int gx = 0, gy = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvArgs a = list[i];
+    if (a.taps != 9 || a.prec != 1 || a.in0.fmt != 0 || a.store == ST_S16P || a.store == ST_S16P_POOL) return -1000;
+    if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return -1000;
+    if ((long)a.H * a.W * (a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps) * 4 >= 0x7ffffff0L) return -1000;
+    if (!(a.npad == 32 || a.ng32)) return -1000;                       // 32-channel groups (kp2d_api.cpp: small grids)
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 7) / 8;
+    const int nx = a.tiles_x * a.tiles_y * a.B, ny = a.npad / 32;
+    if ((long)((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B * ny >= 256) return -1000;      // (the condition of the <1,1,8> form)
+    if (a.store == ST_NCHW && ny != 1 && a.act == ACT_SOFTMAX_C) return -1000;
+    gx = nx > gx ? nx : gx;
+    gy = ny > gy ? ny : gy;
+    const size_t l = f_lds_bytes(a, 32, 16, 8, 1);
+    lds = l > lds ? l : lds;
+    m.a[i] = a;
+  }
+  static PerDeviceOnce lds_once;
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_multi_kernel))) return e;
+  g_variant = "<1,1,8>x";
+  hipLaunchKernelGGL(conv3x3_f16x3_multi_kernel, dim3(gx, gy, n), dim3(256), lds, s, m);
+  return (int)hipGetLastError();
+}
 const char* conv3x3_last_variant() { return g_variant; }
 void conv3x3_note_variant(const char* v) { g_variant = v; }
 
@@ -675,7 +919,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.store == ST_S16P_POOL) {
     if (!(a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.cout == 32 && a.act <= ACT_RELU &&
           a.in0.rs == (long)a.W * a.in0.ps && a.in0.ps == 16 && a.in0.o == 0 && conv3x3_ws_would_run(a.B, a.H, a.W, a.ws_min))) return -1006;
-    g_variant = "<ws>s16";
+    g_variant = a.stem_x ? "<ws>stem+s16" : "<ws>s16";
     return launch_ws<true>(a, s);
   }
   // the staging addresses a source pixel as (y * W + x) * pixel stride
@@ -703,7 +947,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (ws_on && a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.store == ST_NHWC_POOL && a.act <= ACT_RELU &&
       !(a.H & 1) && !(a.W & 1) && a.W >= 32 && (long)((a.W + 31) / 32) * ((a.H + 15) / 16) * a.B >= (a.ws_min > 0 ? a.ws_min : 1024) &&
       (long)a.B * a.in0.bs * 4 < 0x7ffffff0L)
-  { g_variant = "<ws>"; return launch_ws<false>(a, s); }
+  { g_variant = a.stem_x ? "<ws>stem" : "<ws>"; return launch_ws<false>(a, s); }
   // 32-channel layers on grids that fill the chip several times: the warp-specialised persistent form with 32-channel items
   if (a.npad == 32 && !a.ng32) {
     const int e = launch_conv3x3_f16x3_wsm(a, s, 32);

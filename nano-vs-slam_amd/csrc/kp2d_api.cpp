@@ -148,6 +148,9 @@ struct kp2d_model {
   int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
   int wsm_tr = 0;         // kp2d_set_option("wsm_transposed")
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
+  bool stem_fusion = !(getenv("KP2D_STEM") && getenv("KP2D_STEM")[0] == '0');    // kp2d_set_option("stem_fusion") (KP2D_STEM=0: the A/B default): conv1a computed inside conv1b's launch on big grids (conv3x3_f16.hip STEM)
+  float conv1a_wscale = 1.f;  // 2^e of the split of conv1a's weights (pack())
+  bool multi_launch = true;   // kp2d_set_option("multi_launch"): independent layers of a level as one launch on small grids
   int s16_min = 0;        // kp2d_set_option("s16_min_items"): conv3x3_s16.hip — 0 = automatic (three rounds of tiles per workgroup), N = from N tiles, < 0 = never
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
@@ -419,6 +422,12 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
     for (int co = 0; co < c1; ++co)
       for (int k = 0; k < nk; ++k) blob[m->conv1a_w + (size_t)k * c1 + co] = w[(size_t)co * nk + k];
     bn_fold(m, "backbone.conv1a.bn", c1, &blob[m->conv1a_sc], &blob[m->conv1a_sh]);
+    // the fused first layer splits these weights as w 2^e (conv3x3_f16.hip STEM): e as for every other layer
+    float wmax = 0.f;
+    for (float v : w) wmax = std::max(wmax, std::fabs(v));
+    int e16 = 11;
+    while (e16 > -96 && wmax * std::ldexp(1.0f, e16) > 32768.0f) --e16;
+    m->conv1a_wscale = std::ldexp(1.0f, e16);
   }
   for (const auto& c : m->convs) {
     std::vector<float> wvirt;
@@ -595,6 +604,32 @@ struct Plan {
   long long* seg_ids = nullptr;     // (kp2d_set_seg_ids): the layer that writes seg also writes its per-pixel argmax
   int nlanes = 1;         // stream lanes of this forward (conv3x3_wsm.hip sizes its grid by it)
   int rc = KP2D_OK;
+  // Independent layers of one level as ONE launch (conv3x3_f16.hip::conv3x3_f16x3_multi_kernel; small grids only): between
+  // group_begin() and group_end() the 3x3 split-fp16 launches are collected instead of enqueued.  Their inputs must not be
+  // released — and no tap taken — before group_end(): the caller's job (build()).
+  const float* stem_x = nullptr;   // the frames, when conv1b's launch computes conv1a itself (build())
+  bool grouping = false;
+  bool no_levels = false;   // dry runs: size the head-by-head schedule too (plan_bytes_uncached takes the larger)
+  std::vector<ConvArgs> pending;
+  std::vector<std::string> pending_names;
+  void group_begin() {
+    if (dry || rc != KP2D_OK || m->profiling || m->tap_dst || !m->multi_launch) return;      // (profiles and taps: one launch per layer)
+    grouping = true;
+  }
+  void group_end() {
+    grouping = false;
+    if (pending.empty()) return;
+    int e = -1000;
+    if (pending.size() >= 2 && rc == KP2D_OK) e = launch_conv3x3_f16x3_multi(pending.data(), (int)pending.size(), stream);
+    if (e == -1000) {
+      for (size_t i = 0; i < pending.size() && rc == KP2D_OK; ++i)
+        check(launch_conv3x3(pending[i], 16, stream), pending_names[i].c_str());
+    } else {
+      check(e, pending_names[0].c_str());
+    }
+    pending.clear();
+    pending_names.clear();
+  }
 
   // kp2d_set_tap: copy activation `a` (this sub-batch's frames) to the caller's planar [B,C,H,W] buffer
   void tap(const std::string& name, const Act& a) {
@@ -667,6 +702,10 @@ struct Plan {
     a.ws_min = m->ws_min;
     a.wsm_lanes = nlanes;
     a.s16_min = m->s16_min;
+    if (stem_x && name == "backbone.conv1b") {
+      a.stem_x = stem_x; a.stem_w = m->blob + m->conv1a_w; a.stem_scale = m->blob + m->conv1a_sc; a.stem_shift = m->blob + m->conv1a_sh;
+      a.stem_wscale = m->conv1a_wscale; a.stem_act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
+    }
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.w_tr = (split && c.w16t_off) ? m->blob + c.w16t_off : nullptr;
     a.tiles_x = (Wc + 15) / 16; a.tiles_y = (Hc + 15) / 16;
@@ -710,6 +749,11 @@ struct Plan {
       prof_begin(name, "conv3x3_head", 2.0 * 9 * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * 9 * c.cin * c.cout);
       check(launch_head3x3(a, stream), name.c_str());
       prof_end();
+      return;
+    }
+    if (grouping && split && c.taps == 9 && pending.size() < 4) {
+      pending.push_back(a);
+      pending_names.push_back(name);
       return;
     }
     const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
@@ -876,8 +920,14 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   const int H = P.H, W = P.W, B = P.B;
 
   // ---- backbone (encoders.py:105-129) ----
-  Act t1a = P.alloc(m->c1, H, W);
-  if (!P.dry && P.rc == KP2D_OK) {
+  // Big grids: conv1a inside conv1b's launch (conv3x3_f16.hip STEM) — its output, the largest tensor of the forward after
+  // `skip`, is never written.  Float frames, RGB, 16 -> 32 first stage, split-fp16 arithmetic, a pooled conv1b on the
+  // warp-specialised form; a tap on conv1a keeps the two launches (the fused layer has no output to copy).
+  const bool stem = m->stem_fusion && m->precision == KP2D_PREC_F16X3 && !o.frames && g.in_channels == 3 && m->c1 == 16 && m->c2 == 32 &&
+                    g.downsample >= 2 && conv3x3_ws_would_run(B, H, W, m->ws_min) && !(m->tap_dst && m->tap_name == "backbone.conv1a");
+  Act t1a = P.alloc(m->c1, H, W);      // (allocated either way: the workspace size must not depend on the input kind or on a tap)
+  if (stem) P.stem_x = o.x;
+  if (!stem && !P.dry && P.rc == KP2D_OK) {
     Conv1aArgs a{};
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
     a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk; a.cin = g.in_channels;
@@ -942,6 +992,108 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     }
     return P.cbr(name, xb, nullptr, ST_NHWC);
   };
+  // NetVLAD / GeM / ConvAP / encoder map behind vlad_head.convlad3 (vpr.py:78-89, netvlad.py:79-106)
+  auto vlad_tail = [&](const Act& v3a) {
+    const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
+    if (only_enc || g.remove_netvlad) {
+      // vpr.py:84-87: remove_netvlad (to_export) returns the encoder map itself whatever the pooler;
+      // only_encoder=True returns l2(map).  Both leave as the NCHW map.
+      if (!P.dry && P.rc == KP2D_OK) {
+        if (!g.remove_netvlad) P.check(launch_l2norm_channels(P.ptr(v3a), (long)B * S, C, P.stream), "vlad_head.l2");
+        P.check(launch_nhwc_to_nchw(P.ptr(v3a), o.vlad, B, C, S, C, 0, P.stream), "vlad_head (encoder map)");
+      }
+    } else if (g.global_descriptor == KP2D_GD_GEM) {
+      if (!P.dry && P.rc == KP2D_OK) {
+        PoolArgs a{P.ptr(v3a), m->blob + m->vecs.at("vlad_head.netvlad.p").off, o.vlad, B, C, Hc, Wc};
+        P.prof_begin("vlad_head.netvlad", "gem", 4.0 * B * S * C, 4.0 * B * S * C);
+        P.check(launch_gem(a, P.stream), "vlad_head.netvlad (GeM)");
+        P.prof_end();
+      }
+    } else if (g.global_descriptor == KP2D_GD_CONVAP) {
+      Act cp = P.pw("vlad_head.netvlad.channel_pool", v3a, ACT_NONE);
+      if (!P.dry && P.rc == KP2D_OK) {
+        PoolArgs a{P.ptr(cp), nullptr, o.vlad, B, C, Hc, Wc};
+        P.prof_begin("vlad_head.netvlad", "convap_pool", 1.0 * B * S * C, 4.0 * B * S * C);
+        P.check(launch_convap_pool(a, P.stream), "vlad_head.netvlad (ConvAP)");
+        P.prof_end();
+      }
+      P.release(cp);
+    } else {
+      const int ns = netvlad_nsplit(S);
+      const int tps = netvlad_tiles_per_slab(S, B);
+      Act part{};
+      part.bytes = (size_t)B * (ns * tps + (tps > 1 ? 1 : 0)) * ((size_t)K * C + K) * sizeof(float);   // tile mode: + the ordered sums
+      part.off = P.arena.alloc(part.bytes);
+      if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
+      if (!P.dry && P.rc == KP2D_OK) {
+        VladArgs a{};
+        a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
+        a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns; a.tps = tps;
+        a.prec = m->precision == KP2D_PREC_F16X3 ? 1 : 0;
+        P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
+        P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
+        P.prof_end();
+      }
+      P.arena.release(part.off, part.bytes);
+    }
+  };
+  // Small grids, the plain V2 configuration (PixelShuffle upsampling, no attention, no depth head): the heads level by
+  // level instead of head by head.  A frame's forward is a chain of dependent launches of ~8-10 us each whatever they compute;
+  // the layers of different heads that wait for the same predecessor go out as ONE launch (Plan::group_begin / group_end),
+  // so the heads cost the length of the longest chain (the segmentation head's eight layers), not the sum of all chains:
+  // 17 launches -> 12 behind the merged first layer.  Same kernels, same arithmetic, per layer.
+  // (a dry run sizes the workspace for whichever schedule keeps more tensors alive — P.no_levels picks; profiles and taps
+  // take the layers one launch at a time)
+  const bool levels = merged && small_grid && !v3 && !g.use_attention && !g.depth && g.upscale_method != KP2D_UP_CONVTRANSPOSE &&
+                      m->precision == KP2D_PREC_F16X3 && m->multi_launch && !P.no_levels &&
+                      (P.dry || (!m->profiling && !m->tap_dst));
+  if (levels) {
+    const std::string L = "seg_head.convs.";
+    Act s1 = first("score_head.convDa"), l1 = first("loc_head.convDa"), d1 = first("desc_head.convA");
+    Act g0 = first(L + "0"), v1 = first("vlad_head.convlad1");
+    P.head_pair("score_head.convDb", s1, ACT_SIGMOID, o.score, "loc_head.convDb", l1, ACT_TANH, o.shift, Hc, Wc);
+    const ConvPack& cB = m->convs[m->conv_index.at("desc_head.convB")];
+    // level 1
+    Act d2 = P.alloc(cB.cout / 4, H2, W2);
+    P.group_begin();
+    P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+    Act g1 = P.cbr(L + "1", g0, nullptr, ST_NHWC_POOL);
+    Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
+    P.group_end();
+    // level 2
+    P.group_begin();
+    Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
+    Act g2 = P.cbr(L + "2", g1, nullptr, ST_NHWC);
+    Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
+    P.group_end();
+    P.release(d2);
+    P.release(g1);
+    P.release(v2);
+    // level 3
+    P.group_begin();
+    P.conv("desc_head.confBb", d3, d3.C, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
+    Act g3 = P.cbr(L + "3", g2, nullptr, ST_NHWC);
+    P.group_end();
+    P.release(d3);
+    P.release(g2);
+    vlad_tail(v3a);
+    P.release(v3a);
+    // the rest of the segmentation head is the critical path: one layer per launch
+    Act g4 = P.cbr(L + "4", g3, nullptr, ST_SHUFFLE);
+    P.release(g3);
+    Act g5 = P.cbr(L + "5", g4, &xb, ST_NHWC);
+    P.release(g4);
+    Act g6 = P.cbr(L + "6", g5, nullptr, ST_SHUFFLE);
+    P.release(g5);
+    Act g7 = P.cbr(L + "7", g6, &skip, ST_NHWC);
+    P.release(g6);
+    P.conv(L + "8", g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
+    P.release(g7);
+    P.release(mx);
+    P.release(xb);
+    P.release(skip);
+    return;
+  }
   // ---- score / location heads (heads.py:28-35; sigmoid/tanh kp2dtiny.py:574-575, :927-935) ----
   if (only_enc) {
   } else if (v3) {
@@ -1052,48 +1204,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(v1);
     Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
     P.release(v2);
-    const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
-    if (only_enc || g.remove_netvlad) {
-      // vpr.py:84-87: remove_netvlad (to_export) returns the encoder map itself whatever the pooler;
-      // only_encoder=True returns l2(map).  Both leave as the NCHW map.
-      if (!P.dry && P.rc == KP2D_OK) {
-        if (!g.remove_netvlad) P.check(launch_l2norm_channels(P.ptr(v3a), (long)B * S, C, P.stream), "vlad_head.l2");
-        P.check(launch_nhwc_to_nchw(P.ptr(v3a), o.vlad, B, C, S, C, 0, P.stream), "vlad_head (encoder map)");
-      }
-    } else if (g.global_descriptor == KP2D_GD_GEM) {
-      if (!P.dry && P.rc == KP2D_OK) {
-        PoolArgs a{P.ptr(v3a), m->blob + m->vecs.at("vlad_head.netvlad.p").off, o.vlad, B, C, Hc, Wc};
-        P.prof_begin("vlad_head.netvlad", "gem", 4.0 * B * S * C, 4.0 * B * S * C);
-        P.check(launch_gem(a, P.stream), "vlad_head.netvlad (GeM)");
-        P.prof_end();
-      }
-    } else if (g.global_descriptor == KP2D_GD_CONVAP) {
-      Act cp = P.pw("vlad_head.netvlad.channel_pool", v3a, ACT_NONE);
-      if (!P.dry && P.rc == KP2D_OK) {
-        PoolArgs a{P.ptr(cp), nullptr, o.vlad, B, C, Hc, Wc};
-        P.prof_begin("vlad_head.netvlad", "convap_pool", 1.0 * B * S * C, 4.0 * B * S * C);
-        P.check(launch_convap_pool(a, P.stream), "vlad_head.netvlad (ConvAP)");
-        P.prof_end();
-      }
-      P.release(cp);
-    } else {
-      const int ns = netvlad_nsplit(S);
-      const int tps = netvlad_tiles_per_slab(S, B);
-      Act part{};
-      part.bytes = (size_t)B * (ns * tps + (tps > 1 ? 1 : 0)) * ((size_t)K * C + K) * sizeof(float);   // tile mode: + the ordered sums
-      part.off = P.arena.alloc(part.bytes);
-      if (part.off == (size_t)-1 && P.rc == KP2D_OK) P.rc = fail(KP2D_ERR_WORKSPACE, "workspace exhausted");
-      if (!P.dry && P.rc == KP2D_OK) {
-        VladArgs a{};
-        a.x = P.ptr(v3a); a.wa = m->blob + m->vlad_wa; a.cent = m->blob + m->vlad_cent;
-        a.part = P.ptr(part); a.out = o.vlad; a.B = B; a.S = S; a.C = C; a.K = K; a.nsplit = ns; a.tps = tps;
-        a.prec = m->precision == KP2D_PREC_F16X3 ? 1 : 0;
-        P.prof_begin("vlad_head.netvlad", "netvlad", 2.0 * 2 * K * C * (double)B * S, 4.0 * B * ((double)S * C + K * C));
-        P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
-        P.prof_end();
-      }
-      P.arena.release(part.off, part.bytes);
-    }
+    vlad_tail(v3a);
     P.release(v3a);
   }
   if (merged) P.release(mx);
@@ -1141,7 +1252,13 @@ size_t plan_bytes_uncached(kp2d_model* m, int Bc, int H, int W) {
   P.arena.reset((size_t)1 << 46);
   FwdOut o{};
   build(P, o, 0);
-  return P.rc == KP2D_OK ? P.arena.high : 0;
+  if (P.rc != KP2D_OK) return 0;
+  // the level-by-level schedule of small grids and the head-by-head one keep different tensors alive: room for either
+  Plan Q{};
+  Q.m = m; Q.stream = nullptr; Q.ws = nullptr; Q.dry = true; Q.B = Bc; Q.H = H; Q.W = W; Q.no_levels = true;
+  Q.arena.reset((size_t)1 << 46);
+  build(Q, o, 0);
+  return Q.rc == KP2D_OK ? std::max(P.arena.high, Q.arena.high) : 0;
 }
 
 }  // namespace
@@ -1538,6 +1655,34 @@ int kp2d_match_pairs(const int32_t* match_q, const float* match_d, const float* 
   return KP2D_OK;
 }
 
+int kp2d_match_topk_pairs(int mode, const int32_t* match_q, const int64_t* matches0, const float* val, const float* pts0,
+                          const float* pts1, int B, int max0, int max1, int k, float* pairs, int32_t* idx, float* out_val,
+                          int32_t* count, void* scratch, size_t scratch_bytes, void* stream) {
+  if (mode != KP2D_TOPK_BF && mode != KP2D_TOPK_LG) return fail(KP2D_ERR_ARG, "mode is KP2D_TOPK_BF or KP2D_TOPK_LG");
+  if (!val || !count || !scratch || (mode == KP2D_TOPK_BF ? !match_q : !matches0) || (pairs && (!pts0 || !pts1)))
+    return fail(KP2D_ERR_ARG, "null argument");
+  if (B < 1 || max0 < 1 || max1 < 1) return fail(KP2D_ERR_ARG, "empty match problem");
+  const int n = mode == KP2D_TOPK_BF ? max1 : max0;
+  const int kcap = (k <= 0 || k > n) ? n : k;
+  if (scratch_bytes < kp2d_match_topk_scratch_bytes(B, max0, max1)) return fail(KP2D_ERR_WORKSPACE, "match top-k scratch too small");
+  if (reinterpret_cast<uintptr_t>(scratch) & 3) return fail(KP2D_ERR_ARG, "match top-k scratch must be 4-byte aligned");
+  DeviceGuard guard(val, (hipStream_t)stream);
+  TopkPairsArgs a{};
+  a.mode = mode; a.match_q = match_q; a.matches0 = reinterpret_cast<const long long*>(matches0); a.val = val;
+  a.pts0 = pts0; a.pts1 = pts1; a.B = B; a.n = n; a.max0 = max0; a.max1 = max1; a.kcap = kcap;
+  a.keys = static_cast<float*>(scratch);
+  a.sel = reinterpret_cast<int32_t*>(a.keys + (size_t)B * n);
+  a.pairs = pairs; a.idx = idx; a.out_val = out_val; a.count = count;
+  int e = launch_match_topk_pairs(a, (hipStream_t)stream);
+  if (e) return fail(KP2D_ERR_HIP, "match top-k pairs: %d", e);
+  return KP2D_OK;
+}
+
+size_t kp2d_match_topk_scratch_bytes(int B, int max0, int max1) {
+  const size_t n = (size_t)(max0 > max1 ? max0 : max1);
+  return (size_t)(B > 0 ? B : 0) * n * 8;      // keys [B][n] float + selection [B][<= n] int32
+}
+
 int kp2d_set_profiling(kp2d_model* m, int on) {
   if (!m) return fail(KP2D_ERR_ARG, "null model");
   m->profiling = on != 0;
@@ -1595,6 +1740,16 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "s16_min_items") {     // conv3x3_s16.hip (split activations through the backbone's 32-channel stage): 0 automatic, N from N tiles, -1 never
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "s16_min_items out of range");
     m->s16_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "stem_fusion") {       // 1 (default): big grids compute conv1a inside conv1b's launch; 0: always two launches
+    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "stem_fusion is 0 or 1");
+    m->stem_fusion = value != 0;
+    return KP2D_OK;
+  }
+  if (k == "multi_launch") {      // 1 (default): layers of different heads that wait for the same predecessor run as one launch on small grids
+    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "multi_launch is 0 or 1");
+    m->multi_launch = value != 0;
     return KP2D_OK;
   }
   if (k == "ws_min_tiles") {

@@ -58,6 +58,9 @@ struct ConvArgs {
   long long* ids_out;                 // ST_NCHW, one channel group: also write argmax over the stored channels per pixel, [B][H][W] int64 (nullptr: no)
   int ws_min;                         // least tiles for the warp-specialised conv1b form (0: 1024)
   int wsm_grid;                       // most workgroups of that form per launch; 0: KP2D_WSM_GRID or one per CU
+  // conv1b's warp-specialised form with conv1a computed by its staging waves (conv3x3_f16.hip STEM): the frames [B,3,H,W] and
+  // conv1a's weights [27][16] / folded BatchNorm; in0 is then unused.  nullptr: conv1a is its own launch
+  const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_shift; float stem_wscale; int stem_act;
   int s16_min;                        // conv3x3_s16.hip: least work items for the form (0: automatic, three rounds per workgroup)
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
@@ -80,6 +83,8 @@ int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, i
 int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s);   // a 1-channel and a 2-channel head, one launch
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)
+// 2-4 independent small-grid layers as one launch; -1000: not all of them are layers of the single-frame form
+int launch_conv3x3_f16x3_multi(const ConvArgs* list, int n, hipStream_t s);
 // conv3x3_wsm.hip: the same layers, 64-channel groups, warp-specialised and persistent; -1000 = not eligible / fewer than min_items work items
 int launch_conv3x3_f16x3_wsm(const ConvArgs& a, hipStream_t s, int n_item);   // n_item: 64 (64-channel groups) or 32 (32-channel layers)
 // conv3x3_s16.hip: 32-input-channel layers whose input is an S16P tensor (in0.fmt == 1); -1000: in0 is not S16P
@@ -161,6 +166,7 @@ struct AttnArgs {
   // v_off C, out_stride C).  The LightGlue blocks read q, k, v as slices of one [q|k|v] or [qk|v] row.
   int q_stride = 0, kv_stride = 0, k_off = 0, v_off = 0, out_stride = 0;
   int prec = 0;        // 1: split-fp16 operands on v_mfma_f32_32x32x16_f16 (head dim <= 16), 0: exact fp32 MFMA
+  const int32_t* tcount = nullptr;   // [B] keys that exist in batch item b's key / value sequence (the rest of its T rows is padding), null: all T
   int kv_bshift = 0;   // keys / values of batch item b come from item (b + kv_bshift) % B (LightGlue cross attention
                        // of both directions in one launch: items [0,B/2) are image 0, [B/2,B) image 1)
 };
@@ -218,6 +224,7 @@ struct LgAssignArgs {
   float* rp_m; float* rp_s; float* cp_m; float* cp_s;      // log-sum-exp partials of sim (maximum, sum of exp)
   float* rmax; int* rarg; float* cmax; int* carg;          // max / argmax partials of the final scores
   float th;                                 // filter_threshold
+  const int32_t* cnt0 = nullptr; const int32_t* cnt1 = nullptr;   // [B] keypoints that exist in each set (rows past them are padding), null: M / N
   int64_t* matches0; int64_t* matches1; float* mscores0; float* mscores1;
 };
 int launch_lg_assign(const LgAssignArgs& a, hipStream_t s);
@@ -248,6 +255,15 @@ struct PairsArgs {       // compaction of the matched rows of every pair (train 
   int32_t* count;        // [B]
 };
 int launch_match_pairs(const PairsArgs& a, hipStream_t s);
+struct TopkPairsArgs {   // at most kcap matched pairs per frame pair, best first (the VO loop's top_k_matches)
+  int mode;              // 0: BF (match_q [B][n] + match distance, smaller is better; n = max1)   1: LightGlue (matches0 [B][n] int64 + matching score; n = max0)
+  const int32_t* match_q; const long long* matches0; const float* val;
+  const float* pts0; const float* pts1;
+  int B, n, max0, max1, kcap;
+  float* keys; int32_t* sel;       // scratch [B][n] / [B][kcap]
+  float* pairs; int32_t* idx; float* out_val; int32_t* count;
+};
+int launch_match_topk_pairs(const TopkPairsArgs& a, hipStream_t s);
 int launch_match(const MatchArgs& a, hipStream_t s);
 
 // ---- small layout / elementwise kernels -----------------------------------------------------

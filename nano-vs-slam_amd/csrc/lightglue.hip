@@ -451,6 +451,7 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lg_sm[];             // at[D][64] | bt[D][64] | tile[64][LG_TP]
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, D = a.D, M = a.M, N = a.N;
+  const int Mv = a.cnt0 ? min(M, a.cnt0[b]) : M, Nv = a.cnt1 ? min(N, a.cnt1[b]) : N;      // keypoints that exist (the rest is padding)
   float* const at = lg_sm;                   // [k][row]
   float* const bt = at + 64 * D;
   float* const tile = bt + 64 * D;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(const LgAssignArgs a) {
     for (int c = 0; c < 4; ++c) {
       tile[(4 * ty + r) * LG_TP + 4 * tx + c] = acc[r][c];
       const int i = i0 + 4 * ty + r, j = j0 + 4 * tx + c;
-      if (i >= M || j >= N) acc[r][c] = -INFINITY;            // outside the inner block: no weight in the sums below
+      if (i >= Mv || j >= Nv) acc[r][c] = -INFINITY;          // outside the inner block / padding rows: no weight in the sums below
     }
   // rows: the 16 threads of a row group are 16 adjacent lanes
   const int TN = gridDim.x, TM = gridDim.y;
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
   __shared__ float tile[64 * LG_TP];
   const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, M = a.M, N = a.N, TN = gridDim.x, TM = gridDim.y;
+  const int Mv = a.cnt0 ? min(M, a.cnt0[b]) : M, Nv = a.cnt1 ? min(N, a.cnt1[b]) : N;
   float* sc = a.scores + (size_t)b * (M + 1) * (N + 1);
   const float* z0p = a.fz + (size_t)b * M * a.fs + a.D;                          // matchability logits of image 0
   const float* z1p = a.fz + ((size_t)a.B * M + (size_t)b * N) * a.fs + a.D;      // ... of image 1
@@ -672,7 +674,8 @@ __global__ __launch_bounds__(256) void lg_finalize_kernel(const LgAssignArgs a) 
       float x = -INFINITY;
       if (i < M && j < N) {
         float* p = &tile[(4 * ty + r) * LG_TP + 4 * tx + c];
-        x = 2.f * *p + base - s_col[4 * tx + c] + s_ls1[4 * tx + c];
+        // (a padding row / column: -inf — no assignment mass, never a maximum)
+        if (i < Mv && j < Nv) x = 2.f * *p + base - s_col[4 * tx + c] + s_ls1[4 * tx + c];
         *p = x;
       }
       v[r][c] = x;
@@ -745,7 +748,14 @@ __global__ __launch_bounds__(256) void lg_filter_kernel(const LgAssignArgs a) {
     float mx;
     return best_of_partials(a.cmax + (size_t)b * TM * N + j, a.carg + (size_t)b * TM * N + j, TM, N, mx);
   };
-  if (e < M) {
+  const int Mv = a.cnt0 ? min(M, a.cnt0[b]) : M, Nv = a.cnt1 ? min(N, a.cnt1[b]) : N;
+  if (e < M && (e >= Mv || Nv == 0)) {              // a padding row, or nothing to match against
+    a.mscores0[(size_t)b * M + e] = 0.f;
+    a.matches0[(size_t)b * M + e] = -1;
+  } else if (e >= M && e < M + N && (e - M >= Nv || Mv == 0)) {
+    a.mscores1[(size_t)b * N + e - M] = 0.f;
+    a.matches1[(size_t)b * N + e - M] = -1;
+  } else if (e < M) {
     float mx;
     const int j = row_best(e, mx);
     const bool mutual = col_best(j) == e;

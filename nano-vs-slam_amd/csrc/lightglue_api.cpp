@@ -201,7 +201,7 @@ int pack(kp2d_lg* m, std::vector<float>& blob) {
 }
 
 struct Ws {
-  size_t x, t3, ctx, msg, hb, cs, fz, rp_m, rp_s, cp_m, cp_s, rmax, rarg, cmax, carg, total;
+  size_t x, t3, ctx, msg, hb, cs, fz, rp_m, rp_s, cp_m, cp_s, rmax, rarg, cmax, carg, cnt, total;
 };
 Ws layout(const kp2d_lg* m, int B, int M, int N) {
   const size_t R = (size_t)B * (M + N), d = m->cfg.descriptor_dim, hd = d / m->cfg.num_heads;
@@ -213,6 +213,7 @@ Ws layout(const kp2d_lg* m, int B, int M, int N) {
   const size_t rp = (size_t)B * ((N + 63) / 64) * M, cp = (size_t)B * ((M + 63) / 64) * N;      // per-tile partials
   w.rp_m = take(rp); w.rp_s = take(rp); w.cp_m = take(cp); w.cp_s = take(cp);
   w.rmax = take(rp); w.rarg = take(rp); w.cmax = take(cp); w.carg = take(cp);
+  w.cnt = take((size_t)2 * B);      // [n0 | n1]: key counts of the 2B sequences (kp2d_lg_forward_counts)
   w.total = off;
   return w;
 }
@@ -292,6 +293,18 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
                     const float* size0, const float* size1, int B, int M, int N, float filter_threshold,
                     float* log_assignment, int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
                     float* ref_desc0, float* ref_desc1, void* workspace, size_t workspace_bytes, void* stream) {
+  return kp2d_lg_forward_counts(m, kpts0, kpts1, desc0, desc1, size0, size1, nullptr, nullptr, B, M, N, filter_threshold,
+                                log_assignment, matches0, matches1, mscores0, mscores1, ref_desc0, ref_desc1, workspace,
+                                workspace_bytes, stream);
+}
+
+int kp2d_lg_forward_counts(kp2d_lg* m, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                           const float* size0, const float* size1, const int32_t* n0, const int32_t* n1, int B, int M, int N,
+                           float filter_threshold, float* log_assignment, int64_t* matches0, int64_t* matches1,
+                           float* mscores0, float* mscores1, float* ref_desc0, float* ref_desc1, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if ((n0 == nullptr) != (n1 == nullptr)) return fail(KP2D_ERR_ARG, "keypoint counts must be given for both sets or neither");
+  if (n0 && (!size0 || !size1)) return fail(KP2D_ERR_ARG, "padded keypoint sets need the image sizes (the default derives them from every row)");
   if (!m || !kpts0 || !kpts1 || !desc0 || !desc1 || !log_assignment || !workspace) return fail(KP2D_ERR_ARG, "null argument");
   if (!matches0 || !matches1 || !mscores0 || !mscores1) return fail(KP2D_ERR_ARG, "null match outputs");
   if (!m->finalized) return fail(KP2D_ERR_STATE, "weights not finalised (kp2d_lg_finalize_weights)");
@@ -307,6 +320,12 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
   const int d = m->cfg.descriptor_dim, din = m->cfg.input_dim, heads = m->cfg.num_heads, hd = d / heads;
   const int R = B * (M + N), R0 = B * M;
   float *X = F(w.x), *T3 = F(w.t3), *CTX = F(w.ctx), *MSG = F(w.msg), *HB = F(w.hb), *CS = F(w.cs), *FZ = F(w.fz);
+  // padded keypoint sets: [n0 | n1] as the key counts of the 2B sequences the attention launches walk
+  int32_t* CNT = n0 ? reinterpret_cast<int32_t*>(base + w.cnt) : nullptr;
+  if (n0) {
+    HIP_TRY(hipMemcpyAsync(CNT, n0, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(CNT + B, n1, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  }
   const float* blob = m->blob;
   int e;
 #define LG_CHECK(call, what)                                                                                    \
@@ -384,6 +403,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
       if (M == N) {   // both images as one batch of 2B sequences
         AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
         t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d; t.prec = 1;
+        t.tcount = CNT;
         LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
       } else {
         for (int set = 0; set < 2; ++set) {
@@ -392,6 +412,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
           AttnArgs t{T3 + r0 * 3 * d, T3 + r0 * 3 * d, CTX + r0 * d, B, n, n, d, heads, scale};
           t.q_stride = 3 * d; t.kv_stride = 3 * d; t.k_off = d; t.v_off = 2 * d; t.out_stride = d;
           t.prec = 1;      // split-fp16 MFMA (fp32-grade, attention.hip): 3x faster than the fp32 16x16x4 kernel at head dim 8
+          t.tcount = CNT ? CNT + (set ? B : 0) : nullptr;
           LG_CHECK(launch_attention(t, st), "self_attn.inner_attn");
         }
       }
@@ -413,6 +434,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
         AttnArgs t{T3, T3, CTX, 2 * B, M, M, d, heads, scale};
         t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d; t.prec = 1;
         t.kv_bshift = B;
+        t.tcount = CNT;
         LG_CHECK(launch_attention(t, st), "cross_attn");
       } else {
         for (int set = 0; set < 2; ++set) {
@@ -420,6 +442,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
           AttnArgs t{T3 + rq * 2 * d, T3 + rk * 2 * d, CTX + rq * d, B, set ? N : M, set ? M : N, d, heads, scale};
           t.q_stride = 2 * d; t.kv_stride = 2 * d; t.k_off = 0; t.v_off = d; t.out_stride = d;
           t.prec = 1;
+          t.tcount = CNT ? CNT + (set ? 0 : B) : nullptr;      // the keys are the OTHER set's rows
           LG_CHECK(launch_attention(t, st), "cross_attn");
         }
       }
@@ -446,6 +469,7 @@ int kp2d_lg_forward(kp2d_lg* m, const float* kpts0, const float* kpts1, const fl
     g.rmax = F(w.rmax); g.cmax = F(w.cmax);
     g.rarg = reinterpret_cast<int*>(base + w.rarg); g.carg = reinterpret_cast<int*>(base + w.carg);
     g.th = filter_threshold;
+    g.cnt0 = n0; g.cnt1 = n1;
     g.matches0 = matches0; g.matches1 = matches1; g.mscores0 = mscores0; g.mscores1 = mscores1;
     LG_CHECK(launch_lg_assign(g, st), "log_assignment");
   }

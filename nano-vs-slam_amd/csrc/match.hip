@@ -484,6 +484,50 @@ int launch_match(const MatchArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// ---- the top_k_matches cap of the VO loop (visual_odometry.py:260-266, :272-283): keys -> launch_topk (post.hip) -> gather ----
+// key of source row r: the value to rank by, larger = better (BF: minus the match distance; LightGlue: the matching score),
+// -inf for rows without a match (kp2d_select_topk's `score > thr` with thr = -inf drops exactly those)
+__global__ __launch_bounds__(256) void match_topk_keys_kernel(const TopkPairsArgs a) {
+  const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n) return;
+  const size_t o = (size_t)b * a.n + r;
+  const bool on = a.mode == 0 ? a.match_q[o] >= 0 : a.matches0[o] >= 0;
+  const float v = a.val[o];
+  a.keys[o] = on ? (a.mode == 0 ? -v : v) : -INFINITY;
+}
+// selected source row sel[i] -> (row in set 0, row in set 1), the pair's coordinates and its value
+__global__ __launch_bounds__(256) void match_topk_gather_kernel(const TopkPairsArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.kcap) return;
+  const size_t oo = (size_t)b * a.kcap + i;
+  const int r = i < a.count[b] ? a.sel[oo] : -1;
+  int r0 = -1, r1 = -1;
+  float v = 0.f;
+  if (r >= 0) {
+    const size_t o = (size_t)b * a.n + r;
+    if (a.mode == 0) { r0 = a.match_q[o]; r1 = r; } else { r0 = r; r1 = (int)a.matches0[o]; }
+    v = a.val[o];
+  }
+  if (a.idx) { a.idx[2 * oo] = r0; a.idx[2 * oo + 1] = r1; }
+  if (a.out_val) a.out_val[oo] = v;
+  if (a.pairs) {
+    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 0) {
+      const float2 p0 = reinterpret_cast<const float2*>(a.pts0)[(size_t)b * a.max0 + r0];
+      const float2 p1 = reinterpret_cast<const float2*>(a.pts1)[(size_t)b * a.max1 + r1];
+      pr = make_float4(p0.x, p0.y, p1.x, p1.y);
+    }
+    reinterpret_cast<float4*>(a.pairs)[oo] = pr;
+  }
+}
+int launch_match_topk_pairs(const TopkPairsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(match_topk_keys_kernel, dim3((a.n + 255) / 256, a.B), dim3(256), 0, s, a);
+  TopkArgs t{a.keys, a.B, a.n, a.kcap, -INFINITY, a.sel, nullptr, a.count};
+  if (int e = launch_topk(t, s)) return e;
+  hipLaunchKernelGGL(match_topk_gather_kernel, dim3((a.kcap + 255) / 256, a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 int launch_match_pairs(const PairsArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(match_pairs_kernel, dim3(a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();

@@ -108,6 +108,7 @@ class LightGlue(nn.Module):
         self._handle = None
         self._sig = None
         self._ws = None
+        self._ws_call = None               # a caller's own workspace for the forwards inside using_workspace()
         if weights_path is not None:
             self.load_state_dict(torch.load(weights_path, map_location="cpu", weights_only=True))
 
@@ -136,6 +137,24 @@ class LightGlue(nn.Module):
             _lib.check(lib.kp2d_lg_finalize_weights(h))
             self._sig = sig
         return lib, self._handle[0]
+
+    def using_workspace(self, ws):
+        """Context manager: forwards inside take ``ws`` (a uint8 device tensor, grown by the caller) instead of the module's
+        cached workspace — one buffer per slot for streams that keep several forwards in flight (pipeline.FrameStream)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._ws_call = self._ws_call, ws
+            try:
+                yield
+            finally:
+                self._ws_call = prev
+        return cm()
+
+    def workspace_bytes(self, b, m, n, device):
+        lib, h = self._engine(torch.device(device))
+        return int(lib.kp2d_lg_workspace_bytes(h, b, m, n))
 
     def _free(self):
         if getattr(self, "_handle", None) is not None:
@@ -188,6 +207,20 @@ class LightGlue(nn.Module):
             return (size.expand(b, 2) if size.dim() == 1 else size).contiguous()
 
         size0, size1 = image_size("view0"), image_size("view1")
+        # extension of this build: padded keypoint sets.  data["num_keypoints0" / "num_keypoints1"] ([B] int32) say how many
+        # rows of each set exist; the rest is padding (no key in any attention, no assignment mass, matches -1).  The
+        # reference gets exactly the selected rows (a new shape every frame, visual_odometry.py:198-258); a replayed HIP
+        # graph needs static shapes (pipeline.FrameStream(match="lightglue")).
+        cnt0, cnt1 = data.get("num_keypoints0"), data.get("num_keypoints1")
+        if (cnt0 is None) != (cnt1 is None):
+            raise ValueError("num_keypoints0 and num_keypoints1 go together")
+        if cnt0 is not None:
+            if size0 is None or size1 is None:
+                raise ValueError("padded keypoint sets need view0 / view1 image_size")
+            cnt0 = cnt0.to(device=dev, dtype=torch.int32).contiguous()
+            cnt1 = cnt1.to(device=dev, dtype=torch.int32).contiguous()
+            if cnt0.numel() != b or cnt1.numel() != b:
+                raise ValueError("num_keypoints0 / num_keypoints1 must hold one count per pair")
         f32 = lambda t: t.to(torch.float32).contiguous()
         kpts0, kpts1, desc0, desc1 = f32(kpts0), f32(kpts1), f32(desc0), f32(desc1)
         d = self.conf.descriptor_dim
@@ -198,13 +231,19 @@ class LightGlue(nn.Module):
         ref = torch.empty(b * (m + n), d, device=dev)      # one buffer: the library copies both images' rows at once
         ref0, ref1 = ref[:b * m].view(b, m, d), ref[b * m:].view(b, n, d)
         need = lib.kp2d_lg_workspace_bytes(h, b, m, n)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self._ws_call is not None:
+            if self._ws_call.numel() < need or self._ws_call.device != dev:
+                raise RuntimeError(f"using_workspace(): the buffer holds {self._ws_call.numel()} bytes, the forward needs {need}")
+            ws = self._ws_call
+        else:
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = self._ws
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.kp2d_lg_forward(h, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(size0), _ptr(size1),
-                                       b, m, n, float(self.conf.filter_threshold), _ptr(scores), _ptr(m0), _ptr(m1),
-                                       _ptr(ms0), _ptr(ms1), _ptr(ref0), _ptr(ref1), _ptr(self._ws), self._ws.numel(),
-                                       C.c_void_p(stream)))
+        _lib.check(lib.kp2d_lg_forward_counts(h, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(size0), _ptr(size1),
+                                              _ptr(cnt0), _ptr(cnt1), b, m, n, float(self.conf.filter_threshold), _ptr(scores),
+                                              _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(ref0), _ptr(ref1),
+                                              _ptr(ws), ws.numel(), C.c_void_p(stream)))
         # (no pruning is built: every point survives all layers; one fill instead of two ones_like * n)
         prune = torch.full((b * (m + n),), float(self.conf.n_layers), device=dev)
         return {

@@ -86,6 +86,54 @@ def match_pairs(match: dict, pts0: torch.Tensor | None = None, pts1: torch.Tenso
     return out
 
 
+TOPK_BF, TOPK_LG = 0, 1
+
+
+def match_topk_pairs(k: int, pts0: torch.Tensor | None, pts1: torch.Tensor | None, match: dict | None = None,
+                     matches0: torch.Tensor | None = None, scores0: torch.Tensor | None = None, out: dict | None = None):
+    """The VO loop's ``top_k_matches`` cap on the device, fused with the compaction (kp2d_match_topk_pairs; replaces
+    visual_odometry.py:272-283 for the brute-force branch — the k smallest distances — and :26-32 + :260-266 for the
+    LightGlue branch — ``get_matches_scores`` then ``scores.topk(k)``).  Either ``match`` (the dict of
+    ``match_descriptors``) or ``matches0`` [B,M] int64 + ``scores0`` [B,M] (``matches0`` / ``matching_scores0`` of
+    ``LightGlue.forward``).  ``k <= 0``: every match.  Returns ``count`` [B], ``idx`` [B,kcap,2] (row in set 0, row in set
+    1), ``val`` [B,kcap] (distance / score) and — with the keypoints — ``pairs`` [B,kcap,4]; best first.
+    ``out``: the dict of an earlier call with the same shapes (static buffers for graph capture)."""
+    lib = _lib.load()
+    if (match is None) == (matches0 is None):
+        raise ValueError("pass either match= (brute force) or matches0= / scores0= (LightGlue)")
+    if match is not None:
+        mode, src_i, src_l, val = TOPK_BF, match["match_q"], None, match["match_d"]
+        B, max1 = src_i.shape
+        max0 = match["nn_idx"].shape[1]
+        n = max1
+    else:
+        mode, src_i, src_l, val = TOPK_LG, None, matches0.contiguous(), scores0.contiguous().float()
+        if src_l.dtype != torch.int64:
+            raise TypeError("matches0 must be int64 (LightGlue's output)")
+        B, max0 = src_l.shape
+        if pts1 is None:
+            raise ValueError("the LightGlue form needs the keypoints of set 1 for its row count")
+        max1 = pts1.shape[1]
+        n = max0
+    dev = val.device
+    if dev.type != "cuda":
+        raise RuntimeError("match_topk_pairs runs on the HIP device only")
+    kcap = n if (k <= 0 or k > n) else int(k)
+    if out is None:
+        nbytes = int(lib.kp2d_match_topk_scratch_bytes(B, max0, max1))
+        out = {"count": torch.empty(B, dtype=torch.int32, device=dev), "idx": torch.empty(B, kcap, 2, dtype=torch.int32, device=dev),
+               "val": torch.empty(B, kcap, device=dev), "_scratch": torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)}
+        if pts0 is not None:
+            out["pairs"] = torch.empty(B, kcap, 4, device=dev)
+    if pts0 is not None:
+        pts0, pts1 = pts0.contiguous().float(), pts1.contiguous().float()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.kp2d_match_topk_pairs(mode, _ptr(src_i), _ptr(src_l), _ptr(val), _ptr(pts0), _ptr(pts1), B, max0, max1, int(k),
+                                         _ptr(out.get("pairs")), _ptr(out["idx"]), _ptr(out["val"]), _ptr(out["count"]),
+                                         _ptr(out["_scratch"]), out["_scratch"].numel() * 8, C.c_void_p(stream)))
+    return out
+
+
 def _single(des1, des2, **kw):
     d1 = torch.as_tensor(des1, dtype=torch.float32, device="cuda").unsqueeze(0)
     d2 = torch.as_tensor(des2, dtype=torch.float32, device="cuda").unsqueeze(0)

@@ -133,10 +133,20 @@ class FrameStream:
     returns ``(kps0, kps1, dist, out)``: matched keypoints of the previous and of this frame ([m,2] each, the arrays the
     reference hands to its pose estimation) and the match distances; descriptors never leave the device (8 + 4 bytes
     per match over PCIe instead of (8 + 4 C) bytes per keypoint).  The first frame has no predecessor: empty arrays.
+
+    ``match="lightglue", matcher=LightGlue(...)``: the loop's ``use_lg`` branch (visual_odometry.py:198-266, kp2dtiny
+    method): keypoints divided by (W, H) of the network input, ``image_size`` = (H, W) as the reference passes it,
+    ``self.lg(data)`` on the previous and the current frame's rows — padded to the selection's capacity, the counts
+    handed over as ``num_keypoints0/1`` (kp2d_lg_forward_counts) — then ``get_matches_scores`` (:26-32) on the device;
+    ``result()`` returns ``(kps0, kps1, scores, out)``.
+
+    ``top_k_matches=k`` (> 0): the loop's cap — the k smallest distances (:272-283) or, with LightGlue, the k largest
+    matching scores (:260-266) — applied on the device (kp2d_match_topk_pairs), best first; the D2H payload is the capped
+    list.
     """
 
     def __init__(self, net, frame_hw, new_size=None, nn_thresh=0.7, top_k=4000, device="cuda", slots=7, match=False,
-                 ratio_test=0.7, semantic=False):
+                 ratio_test=0.7, semantic=False, matcher=None, top_k_matches=0):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("the frame front-end runs on the HIP device only")
@@ -149,6 +159,21 @@ class FrameStream:
             self.scale = torch.tensor([self.W / float(Ws), self.H / float(Hs)], device=self.dev)
         self.top_k = int(top_k)
         self.slots = int(slots)
+        self.lg = None
+        if isinstance(match, str):
+            if match != "lightglue":
+                raise ValueError("match is True (brute force), False, or 'lightglue'")
+            if matcher is None:
+                raise ValueError("match='lightglue' needs matcher=LightGlue(...)")
+            if semantic:
+                raise ValueError("the LightGlue branch of the loop has no semantic variant (visual_odometry.py:194-198)")
+            self.lg = matcher
+        elif matcher is not None:
+            raise ValueError("matcher= goes with match='lightglue'")
+        self.top_k_matches = int(top_k_matches)
+        self._lg_ws = [None] * int(slots)
+        self._lg_wh = torch.tensor([float(self.W), float(self.H)], device=self.dev)
+        self._lg_size = torch.tensor([float(self.H), float(self.W)], device=self.dev)
         self.match, self.ratio, self.semantic = bool(match), float(ratio_test), bool(semantic)
         if self.semantic and not self.match:
             raise ValueError("semantic=True is a mode of match=True")
@@ -219,11 +244,31 @@ class FrameStream:
 
     def _match_step(self, prev, cur, mo, po):
         """Match slot `prev`'s rows (query) against slot `cur`'s (train) into static buffers: enqueue-only."""
-        from .matching import match_descriptors, match_pairs
+        from .matching import match_descriptors, match_pairs, match_topk_pairs
         rp, rc = self.rows[prev], self.rows[cur]
+        if self.lg is not None:
+            # visual_odometry.py:237-258: keypoints / (W, H) of the network input; image_size = image_tensor.shape[1:] = (H, W)
+            scale = self.scale if self.scale is not None else 1.0      # rows are in the ORIGINAL frame's pixels
+            wh, size = self._lg_wh, self._lg_size                       # (device constants: no host copy inside a capture)
+            data = {"keypoints0": rp["pts"] * scale / wh, "keypoints1": rc["pts"] * scale / wh,
+                    "descriptors0": rp["desc"], "descriptors1": rc["desc"],
+                    "view0": {"image_size": size}, "view1": {"image_size": size},
+                    "num_keypoints0": rp["cnt"], "num_keypoints1": rc["cnt"]}
+            k = rp["pts"].shape[1]
+            need = self.lg.workspace_bytes(1, k, k, self.dev)
+            if self._lg_ws[cur] is None or self._lg_ws[cur].numel() < need:
+                self._lg_ws[cur] = torch.empty(max(need, 256), dtype=torch.uint8, device=self.dev)
+            with self.lg.using_workspace(self._lg_ws[cur]):
+                mo = self.lg(data)
+            po = match_topk_pairs(self.top_k_matches, rp["pts"], rc["pts"], matches0=mo["matches0"],
+                                  scores0=mo["matching_scores0"], out=po)
+            return mo, po
         mo = match_descriptors(rp["desc"], rp["cnt"], rc["desc"], rc["cnt"], self.ratio, cls0=rp.get("cls"),
                                cls1=rc.get("cls"), out=mo)
-        po = match_pairs(mo, rp["pts"], rc["pts"], out=po)
+        if self.top_k_matches > 0:
+            po = match_topk_pairs(self.top_k_matches, rp["pts"], rc["pts"], match=mo, out=po)
+        else:
+            po = match_pairs(mo, rp["pts"], rc["pts"], out=po)
         return mo, po
 
     @torch.no_grad()
@@ -265,15 +310,18 @@ class FrameStream:
                 with torch.cuda.stream(cs):
                     mo, po = self._match_step(prev, s, None, None)      # allocates the static outputs (outside capture)
                 cs.synchronize()
-                k = self.rows[s]["pts"].shape[1]
+                k = po["pairs"].shape[1]                 # the selection's capacity, or the top_k_matches cap
+                vkey = "val" if "val" in po else "dist"
                 mh = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, k, 4).pin_memory(),
                       torch.empty(1, k).pin_memory())
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=cs):
-                    self._match_step(prev, s, mo, po)
+                    mo2, _ = self._match_step(prev, s, None if self.lg is not None else mo, po)
                     mh[0].copy_(po["count"], non_blocking=True)
                     mh[1].copy_(po["pairs"], non_blocking=True)
-                    mh[2].copy_(po["dist"], non_blocking=True)
+                    mh[2].copy_(po[vkey], non_blocking=True)
+                if self.lg is not None:
+                    mo = mo2                                 # (LightGlue's outputs are the tensors of the captured call)
                 self.match_graphs.append(g)
                 self.mhost.append(mh)
                 self.outs[s] = dict(self.outs[s], match=mo, pairs=po, rows=self.rows[s])

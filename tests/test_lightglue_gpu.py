@@ -218,3 +218,118 @@ def test_cfg5_two_view_pipeline_at_full_size():
     assert P.sum(2).max() <= 1 + 1e-4 and P.sum(1).max() <= 1 + 1e-4
     same = m0[1] >= 0
     assert np.array_equal(m0[1][same], np.arange(K)[same])          # identical views: a keypoint can only match itself
+
+
+@pytest.mark.parametrize("name,cap,counts", [("S", 256, [(200, 131), (256, 1), (17, 256)]), ("S", 96, [(96, 96), (40, 0)]),
+                                             ("F", 160, [(100, 160)])])
+def test_lightglue_on_padded_keypoint_sets_equals_the_sliced_sets(name, cap, counts):
+    """kp2d_lg_forward_counts (num_keypoints0 / num_keypoints1: the rows of each set that exist, the rest of the capacity is
+    padding) against the ORACLE run on exactly the existing rows, pair by pair — what the reference's VO loop hands its
+    matcher (visual_odometry.py:198-258: the selected rows, a new shape every frame).  Padding rows must be no keys in any
+    attention and carry no assignment mass: valid rows' matches / scores as the sliced run, padding rows -1 / 0.
+    (Parity unpinned as every LightGlue test: the oracle restates lightglue.py, which cannot be imported here.)"""
+    from lightglue.lightglue_configs import get_light_glue_config
+    th = 0.1
+    conf_in = dict(get_light_glue_config(name), filter_threshold=th)
+    conf = lg.get_config(conf_in)
+    sd = lg.seeded_state_dict(conf)
+    B = len(counts)
+    data = make_data(B, cap, cap, conf["input_dim"], seed=23)
+    # garbage in the padding rows (what a replayed graph's static buffers hold from earlier frames)
+    rng = np.random.default_rng(5)
+    for b, (n0, n1) in enumerate(counts):
+        data["keypoints0"][b, n0:] = rng.random((cap - n0, 2)).astype(np.float32) * 500
+        data["descriptors0"][b, n0:] = rng.standard_normal((cap - n0, conf["input_dim"])).astype(np.float32)
+        data["keypoints1"][b, n1:] = rng.random((cap - n1, 2)).astype(np.float32) * 500
+        data["descriptors1"][b, n1:] = rng.standard_normal((cap - n1, conf["input_dim"])).astype(np.float32)
+    model = product(conf_in, sd)
+    dd = to_dev(data)
+    dd["num_keypoints0"] = torch.tensor([c[0] for c in counts], dtype=torch.int32, device=DEV)
+    dd["num_keypoints1"] = torch.tensor([c[1] for c in counts], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        pred = model(dd)
+    m0, s0 = pred["matches0"].cpu().numpy(), pred["matching_scores0"].cpu().numpy()
+    m1, s1 = pred["matches1"].cpu().numpy(), pred["matching_scores1"].cpu().numpy()
+    compared = 0
+    for b, (n0, n1) in enumerate(counts):
+        assert np.all(m0[b, n0:] == -1) and np.all(s0[b, n0:] == 0) and np.all(m1[b, n1:] == -1) and np.all(s1[b, n1:] == 0)
+        assert np.all(m0[b, :n0] < n1) and np.all(m1[b, :n1] < n0)
+        if n0 == 0 or n1 == 0:
+            assert np.all(m0[b] == -1) and np.all(m1[b] == -1)
+            continue
+        one = {"keypoints0": data["keypoints0"][b:b + 1, :n0], "keypoints1": data["keypoints1"][b:b + 1, :n1],
+               "descriptors0": data["descriptors0"][b:b + 1, :n0], "descriptors1": data["descriptors1"][b:b + 1, :n1],
+               "view0": {"image_size": data["view0"]["image_size"][b:b + 1]}, "view1": {"image_size": data["view1"]["image_size"][b:b + 1]}}
+        ref = lg.forward(one, sd, conf)
+        inner = ref["log_assignment"][0, :-1, :-1]
+        la = pred["log_assignment"][b, :n0, :n1].cpu().numpy()
+        assert np.max(np.abs(la - inner) / (1.0 + np.abs(inner))) < 5e-5
+        if n1 > 1:
+            top2 = np.sort(inner, axis=1)[:, -2:]
+            clear = (top2[:, 1] - top2[:, 0]) > 1e-3
+        else:
+            clear = np.ones(n0, bool)
+        rm0, rs0 = ref["matches0"][0], ref["matching_scores0"][0]
+        near_th = (np.abs(rs0 - th) < 1e-4) & (rs0 > 0)
+        if n0 > 1:
+            top2c = np.sort(inner, axis=0)[-2:, :]
+            clear &= ((top2c[1] - top2c[0]) > 1e-3)[inner.argmax(1)]
+        ok = clear & ~near_th
+        assert np.array_equal(m0[b, :n0][ok], rm0[ok])
+        assert np.max(np.abs(s0[b, :n0][ok] - rs0[ok]), initial=0.0) < 1e-4
+        compared += int(ok.sum())
+    assert compared > 0.5 * sum(min(c) and c[0] for c in counts)
+
+
+def test_match_topk_pairs_caps_the_match_list_on_the_device():
+    """kp2d_match_topk_pairs: the VO loop's top_k_matches cap (visual_odometry.py:272-283: np.argpartition(distance, k)[:k] on
+    the brute-force matches; :26-32 + :260-266: get_matches_scores then scores.topk(k) on LightGlue's) against numpy on the
+    same match tables: the same SET of pairs (the reference's order inside the set is unspecified), best first here, the
+    coordinates gathered, k <= 0 / k > matches = every match."""
+    from nano_vs_slam_amd.matching import match_topk_pairs
+    rng = np.random.default_rng(9)
+    B, n0, n1 = 3, 700, 650
+    pts0 = rng.random((B, n0, 2)).astype(np.float32) * 300
+    pts1 = rng.random((B, n1, 2)).astype(np.float32) * 300
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    # brute force: match_q[t] = query kept for train row t
+    mq = np.full((B, n1), -1, np.int32)
+    md = rng.random((B, n1)).astype(np.float32)
+    for b in range(B):
+        rows = rng.permutation(n1)[:[400, 30, 0][b]]
+        mq[b, rows] = rng.permutation(n0)[:len(rows)]
+    md[0, :8] = 0.25                                            # equal distances: lower source row first
+    match = {"match_q": t(mq), "match_d": t(md), "nn_idx": torch.empty(B, n0, dtype=torch.int32, device=DEV)}
+    for k in (100, 0, 5000):
+        r = match_topk_pairs(k, t(pts0), t(pts1), match=match)
+        cnt = r["count"].cpu().numpy()
+        for b in range(B):
+            rows = np.nonzero(mq[b] >= 0)[0]
+            keep = rows if (k <= 0 or len(rows) <= k) else rows[np.argsort(md[b, rows], kind="stable")[:k]]
+            assert cnt[b] == len(keep)
+            idx = r["idx"][b, :cnt[b]].cpu().numpy()
+            assert set(map(tuple, idx.tolist())) == {(int(mq[b, tt]), int(tt)) for tt in keep}
+            val = r["val"][b, :cnt[b]].cpu().numpy()
+            assert np.all(np.diff(val) >= 0) and np.array_equal(val, md[b, idx[:, 1]])
+            pr = r["pairs"][b, :cnt[b]].cpu().numpy()
+            assert np.array_equal(pr[:, :2], pts0[b, idx[:, 0]]) and np.array_equal(pr[:, 2:], pts1[b, idx[:, 1]])
+            assert np.all(r["idx"][b, cnt[b]:].cpu().numpy() == -1)
+    # LightGlue: matches0[q] = train row matched to query q, matching_scores0[q]
+    m0 = np.full((B, n0), -1, np.int64)
+    sc = rng.random((B, n0)).astype(np.float32)
+    for b in range(B):
+        rows = rng.permutation(n0)[:[500, 12, 1][b]]
+        m0[b, rows] = rng.permutation(n1)[:len(rows)]
+    for k in (64, 0):
+        r = match_topk_pairs(k, t(pts0), t(pts1), matches0=t(m0), scores0=t(sc))
+        cnt = r["count"].cpu().numpy()
+        for b in range(B):
+            rows = np.nonzero(m0[b] > -1)[0]                    # get_matches_scores: m0 = matches0 > -1
+            keep = rows if (k <= 0 or len(rows) <= k) else rows[np.argsort(-sc[b, rows], kind="stable")[:k]]
+            assert cnt[b] == len(keep)
+            idx = r["idx"][b, :cnt[b]].cpu().numpy()
+            assert set(map(tuple, idx.tolist())) == {(int(q), int(m0[b, q])) for q in keep}
+            val = r["val"][b, :cnt[b]].cpu().numpy()
+            assert np.all(np.diff(val) <= 0) and np.array_equal(val, sc[b, idx[:, 0]])
+            pr = r["pairs"][b, :cnt[b]].cpu().numpy()
+            assert np.array_equal(pr[:, :2], pts0[b, idx[:, 0]]) and np.array_equal(pr[:, 2:], pts1[b, idx[:, 1]])
