@@ -400,10 +400,13 @@ __host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (
 // cores, split and written into conv1b's operand image.  conv1a's launch and the 315 MB (64 frames) it writes and conv1b reads
 // back — the largest tensor of the forward after `skip` — disappear.  Two VALU forms of this fusion lost in round 3
 // (profiles/r3_ab_warp_specialised.txt: 529 kFLOP of fp32 FMAs per tile are more cycles of the CU's whole vector ALU than
-// conv1b's matrix work).  Here a staging wave owns a band of 4-5 halo rows: it keeps the band's RGB window (band + 2 rows x 40
-// columns) as fp16 hi / lo planes in a wave-private LDS block laid out [row][x][c0 c1 c2 0] — 8 bytes per pixel, so a lane's
-// B operand of v_mfma_f32_16x16x32_f16 (K = 8 taps x 4 channels: two taps per k-group) is two aligned ds_read_b64 — and
-// runs 11 M-tiles of 16 halo pixels x 16 channels: six MFMAs each (8 taps + the ninth, times the three split terms).
+// conv1b's matrix work).  Here a staging wave owns 153 consecutive halo pixels (a quarter of the 18 x 34, five halo rows): it keeps
+// their RGB window (7 rows x 40 columns) as fp16 hi / lo planes in a wave-private LDS block laid out [row][x][c0 c1 c2 0] — 8 bytes
+// per pixel, so a lane's B operand of v_mfma_f32_16x16x32_f16 (K = 8 taps x 4 channels: two taps per k-group) is two aligned
+// ds_read_b64 — and runs 10 M-tiles of 16 halo pixels x 16 channels, six MFMAs each (8 taps + the ninth, times the three split
+// terms), straight-line: no branch between the M-tiles, two accumulators per M-tile, so that one M-tile's epilogue lies under
+// the next one's products (first form: a branch per M-tile and one accumulation chain — the staging wave's serial chain was
+// 11k cycles per tile and the fused layer took 0.218 ms against 0.097 + 0.137 for the two launches).
 // No barrier beyond the tile's own: the window is wave-private and a wave's LDS instructions execute in order.
 // Arithmetic: split-fp16 products like every other layer of this precision mode (x = xh + xl, w 2^e = wh + wl, fp32
 // accumulate: ~1e-7 relative to the exact fp32 FMA chain of conv1a_kernel) — NOT the bits of the stand-alone conv1a launch,
@@ -419,7 +422,9 @@ struct StemArgs {
 namespace {
 constexpr int ST_XR = 7, ST_XC = 40;                   // window rows (a 5-row band + 2) and columns (x0 - 4 .. x0 + 35)
 constexpr int ST_XPL = ST_XR * ST_XC * 8;              // one plane of a wave's window (2,240 B)
-constexpr int ST_MT = 11;                              // M-tiles of 16 halo pixels per band (5 rows x 34 = 170 pixels)
+constexpr int ST_NPX = WS_ROWS * WS_COLS / 4;          // halo pixels per staging wave: 612 / 4 = 153 consecutive ones (five halo rows)
+constexpr int ST_MT = (ST_NPX + 15) / 16;              // M-tiles of 16 halo pixels per wave (10)
+static_assert(ST_NPX * 4 == WS_ROWS * WS_COLS, "the halo splits evenly over the four staging waves");
 }  // namespace
 
 template <bool S16OUT, bool STEM>
@@ -482,14 +487,14 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
 
   // ---- STEM producer state (see the kernel comment) ----
   const int pw = wave8 - 8;                                                        // staging wave 0..3
-  const int band0 = pw < 2 ? 5 * pw : 10 + 4 * (pw - 2), band_n = pw < 2 ? 5 : 4;  // halo rows [band0, band0 + band_n)
-  const int band_px = band_n * WS_COLS;
+  const int px0 = ST_NPX * (pw & 3);                                               // halo pixels [px0, px0 + 153) of the 18 x 34
+  const int hr0 = px0 / WS_COLS;                                                   // their first halo row (window row 0 = hr0 - 1)
   char* const xw = sm + WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (pw & 3) * 2 * ST_XPL;   // this wave's window: hi plane | lo plane
   float4 rx[STEM ? 2 : 1][STEM ? 4 : 1];
   int tset[2] = {0, 0};                                                            // tile carried by each register set
   f16x8 swh[2], swl[2];                                                            // A operands: taps (2 lg, 2 lg + 1) and tap 8
   float ssc[4], ssh[4];
-  int sbase[STEM ? ST_MT : 1];
+  int sbase[STEM ? ST_MT : 1], simg[STEM ? ST_MT : 1], sprc[STEM ? ST_MT : 1];
   int so0 = 0, so1 = 0;
   const int slg = lane >> 4, slp = lane & 15;
   if constexpr (STEM) {
@@ -515,10 +520,13 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       so1 = toff(2 * slg + 1);
 #pragma unroll
       for (int mt = 0; mt < ST_MT; ++mt) {
-        int p = 16 * mt + slp;
-        p = p < band_px ? p : band_px - 1;
-        const int r = p / WS_COLS, c = p - r * WS_COLS;
-        sbase[mt] = (r * ST_XC + c + 2) * 8;            // window pixel of tap (0, 0): row r, column c + 2 (halo column c = x0 - 1 + c)
+        const int q = 16 * mt + slp;
+        const int hp = px0 + (q < ST_NPX ? q : ST_NPX - 1);      // (lanes past the wave's share read its last pixel and write nothing)
+        const int hr = hp / WS_COLS, hc = hp - hr * WS_COLS;
+        sbase[mt] = ((hr - hr0) * ST_XC + hc + 2) * 8;           // window pixel of tap (0, 0): halo column hc = map column x0 - 1 + hc
+        // (lanes past the share write into pitch column 34 of their row — never read — so that the stores need no branch)
+        simg[mt] = (hr * WS_PITCH + (q < ST_NPX ? hc : WS_COLS)) * F_PXB + slg * 8;
+        sprc[mt] = (hr << 8) | hc;
       }
     }
   }
@@ -531,12 +539,12 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
     const bool live = t < ntiles;
     const int b = t / per_frame, r = t - b * per_frame;
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-    const int gy0 = ty * WS_TH - 2 + band0, gx0 = tx * WS_TW - 4;
+    const int gy0 = ty * WS_TH - 2 + hr0, gx0 = tx * WS_TW - 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = lane + 64 * j, wr = e / 30, rem = e - 30 * wr, c = rem / 10, q = rem - 10 * c;
       const int gy = gy0 + wr, gx = gx0 + 4 * q;
-      const bool ok = live && wr < band_n + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
+      const bool ok = live && wr < ST_XR && gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
       const int off = ok ? (((b * 3 + c) * H + gy) * W + gx) * 4 : OOB;
       rx[STEM ? RS : 0][STEM ? j : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
     }
@@ -566,46 +574,50 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
     const int t = tset[RS];
     const int b = t / per_frame, r = t - b * per_frame;
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-    const int y0 = ty * WS_TH - 1 + band0, x0 = tx * WS_TW - 1;      // map position of the band's first halo pixel
+    const int y0 = ty * WS_TH - 1, x0 = tx * WS_TW - 1;      // map position of halo pixel (0, 0)
+    (void)b;
     const float slope1 = st.act == ACT_LEAKY ? 0.01f : (st.act == ACT_RELU ? 0.f : 1.f);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    char* const img = sm + buf * WS_IMG;
+    // operands of M-tile mt + 1 are read before M-tile mt's products (explicit one-deep pipeline: the reads' latency and the
+    // previous M-tile's epilogue lie under the matrix instructions)
+    h4 na0, na1, nb0, nb1, na8, nb8;
+    auto fetch = [&](int mt) {
+      const char* const ph = xw + sbase[mt];
+      na0 = *reinterpret_cast<const h4*>(ph + so0); na1 = *reinterpret_cast<const h4*>(ph + so1);
+      nb0 = *reinterpret_cast<const h4*>(ph + so0 + ST_XPL); nb1 = *reinterpret_cast<const h4*>(ph + so1 + ST_XPL);
+      na8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8); nb8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8 + ST_XPL);
+    };
+    fetch(0);
 #pragma unroll
     for (int mt = 0; mt < ST_MT; ++mt) {
-      if (16 * mt >= band_px) break;                   // (the 4-row bands: 136 pixels = 9 M-tiles)
-      const char* const ph = xw + sbase[mt];
-      const h4 a0 = *reinterpret_cast<const h4*>(ph + so0), a1 = *reinterpret_cast<const h4*>(ph + so1);
-      const h4 b0 = *reinterpret_cast<const h4*>(ph + so0 + ST_XPL), b1 = *reinterpret_cast<const h4*>(ph + so1 + ST_XPL);
-      const h4 a8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8), b8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8 + ST_XPL);
-      const f16x8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const f16x8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      const f16x8 yh = {a8[0], a8[1], a8[2], a8[3], 0, 0, 0, 0};
-      const f16x8 yl = {b8[0], b8[1], b8[2], b8[3], 0, 0, 0, 0};
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc, 0, 0, 0);
-      // lane (slp, slg): halo pixel 16 mt + slp of the band, channels 4 slg .. 4 slg + 3
-      const int p = 16 * mt + slp;
-      const int pr = p / WS_COLS, pc = p - pr * WS_COLS;
-      const int y = y0 + pr, x = x0 + pc;
-      const bool in = p < band_px && y >= 0 && y < H && x >= 0 && x < W;      // outside the map: conv1b's zero padding
+      const f16x8 xh = {na0[0], na0[1], na0[2], na0[3], na1[0], na1[1], na1[2], na1[3]};
+      const f16x8 xl = {nb0[0], nb0[1], nb0[2], nb0[3], nb1[0], nb1[1], nb1[2], nb1[3]};
+      const f16x8 yh = {na8[0], na8[1], na8[2], na8[3], 0, 0, 0, 0};
+      const f16x8 yl = {nb8[0], nb8[1], nb8[2], nb8[3], 0, 0, 0, 0};
+      if (mt + 1 < ST_MT) fetch(mt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc1, 0, 0, 0);
+      // lane (slp, slg): halo pixel px0 + 16 mt + slp, channels 4 slg .. 4 slg + 3
+      const int y = y0 + (sprc[mt] >> 8), x = x0 + (sprc[mt] & 255);
+      const bool in = y >= 0 && y < H && x >= 0 && x < W;      // outside the map: conv1b's zero padding
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float tt = fmaf(acc[i], ssc[i], ssh[i]);
+        const float tt = fmaf(acc0[i] + acc1[i], ssc[i], ssh[i]);
         v[i] = in ? fmaxf(tt, tt * slope1) : 0.f;
       }
       f16x2 h0, l0, h1, l1;
       split2(v[0], v[1], h0, l0);
       split2(v[2], v[3], h1, l1);
-      if (p < band_px) {
-        const int lb = buf * WS_IMG + ((band0 + pr) * WS_PITCH + pc) * F_PXB + slg * 8;
-        *reinterpret_cast<f16x4*>(sm + lb) = f16x4{h0[0], h0[1], h1[0], h1[1]};
-        *reinterpret_cast<f16x4*>(sm + WS_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
-      }
+      *reinterpret_cast<f16x4*>(img + simg[mt]) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<f16x4*>(img + WS_LO + simg[mt]) = f16x4{l0[0], l0[1], l1[0], l1[1]};
     }
     asm volatile("" ::: "memory");
   };

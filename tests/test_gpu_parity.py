@@ -1126,7 +1126,7 @@ def test_split_activation_backbone_stage_equals_the_fp32_activation_path(config,
         got_taps = {t: model.forward_with_tap(x, t, (64 if t.endswith("3b") else 32, H // 2, W // 2))[1].clone() for t in taps}
         _set_s16(model, 0, 0)
     assert not any("s16" in k for ks in ran_off.values() for k in ks), ran_off
-    assert any("<ws>s16" in k for k in ran_on["backbone.conv1b"]), ran_on["backbone.conv1b"]
+    assert any("<ws>" in k and "s16" in k for k in ran_on["backbone.conv1b"]), ran_on["backbone.conv1b"]
     for layer in ("backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"):
         assert any("<s16>" in k for k in ran_on[layer]), (layer, ran_on[layer])
     for k in ref:
@@ -1179,7 +1179,7 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
         # the 32-channel stage: split activations + LDS-DMA staging (conv3x3_s16.hip); with that form off, the wide tiles
         # (32-channel items of the register-staging persistent form measured slower)
         if form == "auto":
-            assert any("<ws>s16" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
+            assert any("<ws>" in k and "s16" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
             for layer in ("backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"):
                 assert any("<s16>" in k for k in ran[layer]), (layer, ran[layer])
         else:
