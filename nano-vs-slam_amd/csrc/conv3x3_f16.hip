@@ -490,8 +490,11 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   const int px0 = ST_NPX * (pw & 3);                                               // halo pixels [px0, px0 + 153) of the 18 x 34
   const int hr0 = px0 / WS_COLS;                                                   // their first halo row (window row 0 = hr0 - 1)
   char* const xw = sm + WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (pw & 3) * 2 * ST_XPL;   // this wave's window: hi plane | lo plane
-  float4 rx[STEM ? 2 : 1][STEM ? 4 : 1];
-  int tset[2] = {0, 0};                                                            // tile carried by each register set
+  // window loads of ONE tile in flight (requested while the tile before it is computed): slot e = (window row, column quad);
+  // a lane brings all three planes of its slot(s) — slots 0-63 and, lanes 0-5, slots 64-69 — so that a pixel's (c0, c1, c2, 0)
+  // halves leave as one ds_write_b64 per plane
+  float4 rx[STEM ? 6 : 1];
+  int tset = 0;                                                                    // tile the registers carry
   f16x8 swh[2], swl[2];                                                            // A operands: taps (2 lg, 2 lg + 1) and tap 8
   float ssc[4], ssh[4];
   int sbase[STEM ? ST_MT : 1], simg[STEM ? ST_MT : 1], sprc[STEM ? ST_MT : 1];
@@ -532,52 +535,52 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   }
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(STEM ? st.x : a.in0.p), 0, STEM ? (int)((long)a.B * 3 * H * W * 4) : 0, 0x00020000);
-  // loads of tile t's window: slot e = lane + 64 j -> window row e / 30, plane (e % 30) / 10, four columns 4 (e % 10) ..
-  auto stem_request = [&](int t, auto set_c) {
-    constexpr int RS = decltype(set_c)::value;
-    tset[RS] = t;
+  // loads of tile t's window: slot e = lane + 64 u (u = 0, 1; 70 slots) -> window row e / 10, columns 4 (e % 10) .. + 3, three planes
+  auto stem_request = [&](int t) {
+    tset = t;
     const bool live = t < ntiles;
     const int b = t / per_frame, r = t - b * per_frame;
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
     const int gy0 = ty * WS_TH - 2 + hr0, gx0 = tx * WS_TW - 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = lane + 64 * j, wr = e / 30, rem = e - 30 * wr, c = rem / 10, q = rem - 10 * c;
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u, wr = e / 10, q = e - 10 * wr;
       const int gy = gy0 + wr, gx = gx0 + 4 * q;
       const bool ok = live && wr < ST_XR && gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
-      const int off = ok ? (((b * 3 + c) * H + gy) * W + gx) * 4 : OOB;
-      rx[STEM ? RS : 0][STEM ? j : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      const int off = ok ? ((b * 3 * H + gy) * W + gx) * 4 : OOB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rx[STEM ? 3 * u + c : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, c * H * W * 4, 0));
     }
   };
-  auto stem_commit = [&](int buf, auto set_c) {
-    constexpr int RS = decltype(set_c)::value;
-    // window: fp32 -> hi / lo halves at [row][x][c]
+  auto stem_commit = [&](int buf) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    // window: fp32 -> hi / lo halves at [row][x][c0 c1 c2 0]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = lane + 64 * j, wr = e / 30, rem = e - 30 * wr, c = rem / 10, q = rem - 10 * c;
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u, wr = e / 10, q = e - 10 * wr;
       if (wr >= ST_XR) continue;
-      const float4 v = rx[STEM ? RS : 0][STEM ? j : 0];
-      f16x2 h0, l0, h1, l1;
-      split2(v.x, v.y, h0, l0);
-      split2(v.z, v.w, h1, l1);
-      char* const d = xw + (wr * ST_XC + 4 * q) * 8 + c * 2;
-      *reinterpret_cast<_Float16*>(d) = h0[0];
-      *reinterpret_cast<_Float16*>(d + 8) = h0[1];
-      *reinterpret_cast<_Float16*>(d + 16) = h1[0];
-      *reinterpret_cast<_Float16*>(d + 24) = h1[1];
-      *reinterpret_cast<_Float16*>(d + ST_XPL) = l0[0];
-      *reinterpret_cast<_Float16*>(d + ST_XPL + 8) = l0[1];
-      *reinterpret_cast<_Float16*>(d + ST_XPL + 16) = l1[0];
-      *reinterpret_cast<_Float16*>(d + ST_XPL + 24) = l1[1];
+      const float4 v0 = rx[STEM ? 3 * u : 0], v1 = rx[STEM ? 3 * u + 1 : 0], v2 = rx[STEM ? 3 * u + 2 : 0];
+      const float c0[4] = {v0.x, v0.y, v0.z, v0.w}, c1[4] = {v1.x, v1.y, v1.z, v1.w}, c2[4] = {v2.x, v2.y, v2.z, v2.w};
+      char* const d = xw + (wr * ST_XC + 4 * q) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f16x2 ha, la, hb, lb;
+        split2(c0[i], c1[i], ha, la);
+        split2(c2[i], 0.f, hb, lb);
+        *reinterpret_cast<h4*>(d + 8 * i) = h4{ha[0], ha[1], hb[0], hb[1]};
+        *reinterpret_cast<h4*>(d + 8 * i + ST_XPL) = h4{la[0], la[1], lb[0], lb[1]};
+      }
     }
     asm volatile("" ::: "memory");                     // (halves written as fp16 lvalues, read back as 8-byte vectors below)
-    const int t = tset[RS];
+    const int t = tset;
     const int b = t / per_frame, r = t - b * per_frame;
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
     const int y0 = ty * WS_TH - 1, x0 = tx * WS_TW - 1;      // map position of halo pixel (0, 0)
     (void)b;
     const float slope1 = st.act == ACT_LEAKY ? 0.01f : (st.act == ACT_RELU ? 0.f : 1.f);
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    // a tile whose whole halo lies inside the map needs no zero-padding test (wave-uniform: most tiles of a big map)
+    const bool interior = y0 >= 0 && y0 + WS_ROWS <= H && x0 >= 0 && x0 + WS_COLS <= W;
     char* const img = sm + buf * WS_IMG;
     // operands of M-tile mt + 1 are read before M-tile mt's products (explicit one-deep pipeline: the reads' latency and the
     // previous M-tile's epilogue lie under the matrix instructions)
@@ -597,20 +600,21 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       const f16x8 yl = {nb8[0], nb8[1], nb8[2], nb8[3], 0, 0, 0, 0};
       if (mt + 1 < ST_MT) fetch(mt + 1);
       __builtin_amdgcn_sched_barrier(0);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc1, 0, 0, 0);
+      // one accumulation chain (a dependent v_mfma_f32_16x16x32_f16 issues every 16 cycles like an independent one): small terms first
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc, 0, 0, 0);
       // lane (slp, slg): halo pixel px0 + 16 mt + slp, channels 4 slg .. 4 slg + 3
       const int y = y0 + (sprc[mt] >> 8), x = x0 + (sprc[mt] & 255);
-      const bool in = y >= 0 && y < H && x >= 0 && x < W;      // outside the map: conv1b's zero padding
+      const bool in = interior || (y >= 0 && y < H && x >= 0 && x < W);      // outside the map: conv1b's zero padding
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float tt = fmaf(acc0[i] + acc1[i], ssc[i], ssh[i]);
+        const float tt = fmaf(acc[i], ssc[i], ssh[i]);
         v[i] = in ? fmaxf(tt, tt * slope1) : 0.f;
       }
       f16x2 h0, l0, h1, l1;
@@ -782,18 +786,17 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       static_assert(WS_BARRIERS_PER_TRIP == 2, "multiplying loop: two barriers per trip");
     }
   } else if constexpr (STEM) {
-    stem_request(t0, S0{});
-    stem_commit(0, S0{});
-    stem_request(t0 + G, S0{});
-    stem_request(t0 + 2 * G, S1{});
+    stem_request(t0);
+    stem_commit(0);
+    stem_request(t0 + G);
     __syncthreads();
     for (int k = 0; k < trips; ++k) {
       const int t = t0 + 2 * k * G;
-      stem_commit(1, S0{});
-      stem_request(t + 3 * G, S0{});
+      stem_commit(1);                  // tile t + G, requested a tile ago
+      stem_request(t + 2 * G);
       __syncthreads();
-      stem_commit(0, S1{});
-      stem_request(t + 4 * G, S1{});
+      stem_commit(0);                  // tile t + 2 G
+      stem_request(t + 3 * G);
       __syncthreads();
       static_assert(WS_BARRIERS_PER_TRIP == 2, "staging loop (stem): two barriers per trip");
     }

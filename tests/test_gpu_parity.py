@@ -1641,8 +1641,9 @@ def test_frame_stream_runs_lightglue_inside_the_loop():
     lgm = LightGlue(conf_in)
     lgm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     lgm = lgm.to(DEV).eval()
-    H, W, K = 96, 128, 25
-    frames = _vo_frames(6, np.random.default_rng(6), (H, W))
+    # (seeded random matcher weights: a handful of mutual matches per frame — many frames, and a cap small enough to cut)
+    H, W, K = 96, 128, 2
+    frames = _vo_frames(14, np.random.default_rng(6), (H, W))
     rows = [inference(model, f, None, nn_thresh=0.5, top_k=200)[:2] for f in frames]
     fs = FrameStream(model, (H, W), None, nn_thresh=0.5, top_k=200, device=DEV, slots=3, match="lightglue", matcher=lgm,
                      top_k_matches=K)
@@ -1650,7 +1651,7 @@ def test_frame_stream_runs_lightglue_inside_the_loop():
     assert got[0][0].shape == (0, 2)
     wh = np.asarray([W, H], np.float32)
     size = np.asarray([[H, W]], np.float32)
-    compared = agreed = 0
+    compared = agreed = cut = 0
     for i in range(1, len(frames)):
         (p0, f0), (p1, f1) = rows[i - 1], rows[i]
         data = {"keypoints0": (p0 / wh)[None], "keypoints1": (p1 / wh)[None], "descriptors0": f0[None], "descriptors1": f1[None],
@@ -1678,9 +1679,10 @@ def test_frame_stream_runs_lightglue_inside_the_loop():
         if len(on) > K and len(sc):
             left = [q for q in on if (int(q), int(m0[q])) not in gotp]
             assert all(s0[q] <= sc[-1] + 1e-4 for q in left)
+            cut += 1
         else:
             assert abs(len(gotp) - len(on)) <= max(2, len(on) // 20)
-    assert compared >= 8 and agreed >= 60, (compared, agreed)
+    assert compared >= 8 and agreed >= 15 and cut >= 2, (compared, agreed, cut)
 
 
 @pytest.mark.parametrize("B,H,W,tiles", [(1, 304, 864, 513), (1, 80, 96, 15), (1, 112, 1184, 259), (2, 48, 160, 15)])
