@@ -13,7 +13,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv3x3.hip", "conv3x3_f16.hip", "conv3x3_wsm.hip", "conv3x3_s16.hip", "head3x3.hip", "netvlad.hip", "post.hip", "attention.hip", "match.hip", "lightglue.hip", "kp2d_api.cpp",
+SOURCES = ["conv3x3.hip", "conv3x3_f16.hip", "conv3x3_wsm.hip", "conv3x3_s16.hip", "head3x3.hip", "netvlad.hip", "post.hip", "attention.hip", "mff_tail.hip", "match.hip", "lightglue.hip", "kp2d_api.cpp",
            "lightglue_api.cpp"]
 HEADERS = ["kp2d_kernels.h", "device_guard.h", "device_logic.h", "conv_common.h", "conv_epilogue.inc", os.path.join("..", "..", "include", "kp2d.h"),
            os.path.join("..", "..", "include", "kp2d_lightglue.h")]

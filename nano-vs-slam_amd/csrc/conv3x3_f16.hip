@@ -547,7 +547,7 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       const int e = lane + 64 * u, wr = e / 10, q = e - 10 * wr;
       const int gy = gy0 + wr, gx = gx0 + 4 * q;
       const bool ok = live && wr < ST_XR && gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
-      const int off = ok ? ((b * 3 * H + gy) * W + gx) * 4 : OOB;
+      const int off = (ok && !KP2D_DBG_ON(32)) ? ((b * 3 * H + gy) * W + gx) * 4 : OOB;      // (timing ablations: conv_common.h)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         rx[STEM ? 3 * u + c : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, c * H * W * 4, 0));
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = lane + 64 * u, wr = e / 10, q = e - 10 * wr;
-      if (wr >= ST_XR) continue;
+      if (wr >= ST_XR || KP2D_DBG_ON(512)) continue;
       const float4 v0 = rx[STEM ? 3 * u : 0], v1 = rx[STEM ? 3 * u + 1 : 0], v2 = rx[STEM ? 3 * u + 2 : 0];
       const float c0[4] = {v0.x, v0.y, v0.z, v0.w}, c1[4] = {v1.x, v1.y, v1.z, v1.w}, c2[4] = {v2.x, v2.y, v2.z, v2.w};
       char* const d = xw + (wr * ST_XC + 4 * q) * 8;
@@ -582,46 +582,66 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
     // a tile whose whole halo lies inside the map needs no zero-padding test (wave-uniform: most tiles of a big map)
     const bool interior = y0 >= 0 && y0 + WS_ROWS <= H && x0 >= 0 && x0 + WS_COLS <= W;
     char* const img = sm + buf * WS_IMG;
-    // operands of M-tile mt + 1 are read before M-tile mt's products (explicit one-deep pipeline: the reads' latency and the
-    // previous M-tile's epilogue lie under the matrix instructions)
-    h4 na0, na1, nb0, nb1, na8, nb8;
-    auto fetch = [&](int mt) {
+    // M-tiles in PAIRS: the two accumulation chains are interleaved (a dependent MFMA waits for its predecessor's result; the
+    // other M-tile's MFMA fills that slot), the operands of the next pair are read before this pair's products, and the two
+    // epilogues' vector instructions follow the twelve MFMAs as one block
+    h4 na0[2], na1[2], nb0[2], nb1[2], na8[2], nb8[2];
+    auto fetch = [&](int mt, int u) {
       const char* const ph = xw + sbase[mt];
-      na0 = *reinterpret_cast<const h4*>(ph + so0); na1 = *reinterpret_cast<const h4*>(ph + so1);
-      nb0 = *reinterpret_cast<const h4*>(ph + so0 + ST_XPL); nb1 = *reinterpret_cast<const h4*>(ph + so1 + ST_XPL);
-      na8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8); nb8 = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8 + ST_XPL);
+      na0[u] = *reinterpret_cast<const h4*>(ph + so0); na1[u] = *reinterpret_cast<const h4*>(ph + so1);
+      nb0[u] = *reinterpret_cast<const h4*>(ph + so0 + ST_XPL); nb1[u] = *reinterpret_cast<const h4*>(ph + so1 + ST_XPL);
+      na8[u] = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8); nb8[u] = *reinterpret_cast<const h4*>(ph + (2 * ST_XC + 2) * 8 + ST_XPL);
     };
-    fetch(0);
+    static_assert(ST_MT % 2 == 0, "M-tiles are processed in pairs");
+    fetch(0, 0);
+    fetch(1, 1);
 #pragma unroll
-    for (int mt = 0; mt < ST_MT; ++mt) {
-      const f16x8 xh = {na0[0], na0[1], na0[2], na0[3], na1[0], na1[1], na1[2], na1[3]};
-      const f16x8 xl = {nb0[0], nb0[1], nb0[2], nb0[3], nb1[0], nb1[1], nb1[2], nb1[3]};
-      const f16x8 yh = {na8[0], na8[1], na8[2], na8[3], 0, 0, 0, 0};
-      const f16x8 yl = {nb8[0], nb8[1], nb8[2], nb8[3], 0, 0, 0, 0};
-      if (mt + 1 < ST_MT) fetch(mt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      // one accumulation chain (a dependent v_mfma_f32_16x16x32_f16 issues every 16 cycles like an independent one): small terms first
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc, 0, 0, 0);
-      // lane (slp, slg): halo pixel px0 + 16 mt + slp, channels 4 slg .. 4 slg + 3
-      const int y = y0 + (sprc[mt] >> 8), x = x0 + (sprc[mt] & 255);
-      const bool in = interior || (y >= 0 && y < H && x >= 0 && x < W);      // outside the map: conv1b's zero padding
-      float v[4];
+    for (int mt = 0; mt < ST_MT; mt += 2) {
+      if (KP2D_DBG_ON(2048)) break;                    // (ablation: no conv1a products, epilogue or image writes at all)
+      f16x8 xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float tt = fmaf(acc[i], ssc[i], ssh[i]);
-        v[i] = in ? fmaxf(tt, tt * slope1) : 0.f;
+      for (int u = 0; u < 2; ++u) {
+        xh[u] = f16x8{na0[u][0], na0[u][1], na0[u][2], na0[u][3], na1[u][0], na1[u][1], na1[u][2], na1[u][3]};
+        xl[u] = f16x8{nb0[u][0], nb0[u][1], nb0[u][2], nb0[u][3], nb1[u][0], nb1[u][1], nb1[u][2], nb1[u][3]};
+        yh[u] = f16x8{na8[u][0], na8[u][1], na8[u][2], na8[u][3], 0, 0, 0, 0};
+        yl[u] = f16x8{nb8[u][0], nb8[u][1], nb8[u][2], nb8[u][3], 0, 0, 0, 0};
       }
-      f16x2 h0, l0, h1, l1;
-      split2(v[0], v[1], h0, l0);
-      split2(v[2], v[3], h1, l1);
-      *reinterpret_cast<f16x4*>(img + simg[mt]) = f16x4{h0[0], h0[1], h1[0], h1[1]};
-      *reinterpret_cast<f16x4*>(img + WS_LO + simg[mt]) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      if (mt + 2 < ST_MT) { fetch(mt + 2, 0); fetch(mt + 3, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      // (small terms first)
+      if (!KP2D_DBG_ON(128)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh[u], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (KP2D_DBG_ON(1024)) continue;               // (ablation: no epilogue / image writes)
+        // lane (slp, slg): halo pixel px0 + 16 (mt + u) + slp, channels 4 slg .. 4 slg + 3
+        const int y = y0 + (sprc[mt + u] >> 8), x = x0 + (sprc[mt + u] & 255);
+        const bool in = interior || (y >= 0 && y < H && x >= 0 && x < W);      // outside the map: conv1b's zero padding
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tt = fmaf(acc[u][i], ssc[i], ssh[i]);
+          v[i] = in ? fmaxf(tt, tt * slope1) : 0.f;
+        }
+        f16x2 h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0);
+        split2(v[2], v[3], h1, l1);
+        *reinterpret_cast<f16x4*>(img + simg[mt + u]) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<f16x4*>(img + WS_LO + simg[mt + u]) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      }
     }
     asm volatile("" ::: "memory");
   };
@@ -656,6 +676,7 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
 #pragma unroll
       for (int n = 0; n < NN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ib = buf * WS_IMG;
+    if (!KP2D_DBG_ON(8))                               // (timing ablations: conv_common.h)
 #pragma unroll
     for (int slot = 0; slot < 9; slot += 2) {
       const int tp = slot_tap(slot);
@@ -691,6 +712,7 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
         }
       }
     }
+    if (KP2D_DBG_ON(1)) return;
     if constexpr (S16OUT) {
       // lane (lp, lg), tile (m, n): channel 16 n + lp of the pooled pixel (row m / 2, column 4 (m % 2) + lg) of this wave's 2 x 8
       // pooled pixels.  LeakyReLU / ReLU is monotonic, so it is applied once, to the maximum (the same bits as the maximum of

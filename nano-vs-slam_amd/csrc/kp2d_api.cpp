@@ -148,6 +148,7 @@ struct kp2d_model {
   int wsm_grid = 0;       // kp2d_set_option("wsm_grid"): most workgroups per launch of that form (0 = KP2D_WSM_GRID or one per CU)
   int wsm_tr = 0;         // kp2d_set_option("wsm_transposed")
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
+  bool mff_fused = !(getenv("KP2D_MFF") && getenv("KP2D_MFF")[0] == '0');   // kp2d_set_option("mff_fused"): MixFeedForward's tail as one launch (mff_tail.hip)
   bool stem_fusion = !(getenv("KP2D_STEM") && getenv("KP2D_STEM")[0] == '0');    // kp2d_set_option("stem_fusion") (KP2D_STEM=0: the A/B default): conv1a computed inside conv1b's launch on big grids (conv3x3_f16.hip STEM)
   float conv1a_wscale = 1.f;  // 2^e of the split of conv1a's weights (pack())
   bool multi_launch = true;   // kp2d_set_option("multi_launch"): independent layers of a level as one launch on small grids
@@ -853,6 +854,12 @@ struct Plan {
     release(t);
     Act f0 = pw(p + ".mff.fn.net.0", ln2, ACT_NONE);
     release(ln2);
+    if (mff_fusable(C) && f0.C == 128) {
+      Act f3 = mff_tail(p, f0, C, h, w, pool);
+      release(f0);
+      tap(p + ".mff", f3);
+      return f3;
+    }
     Act f1 = alloc(f0.C, h, w);
     if (rc == KP2D_OK && !dry) {
       DwArgs a{ptr(f0), m->blob + m->vecs.at(p + ".mff.fn.net.1.net.0.weight").off,
@@ -868,6 +875,27 @@ struct Plan {
     Act f3 = pw(p + ".mff.fn.net.3", f2, ACT_NONE, pool ? ST_NHWC_POOL : ST_NHWC);
     release(f2);
     tap(p + ".mff", f3);         // pooled when the module folds the following MaxPool2d
+    return f3;
+  }
+  // the same module with MixFeedForward's tail as ONE launch (mff_tail.hip): f16x3 arithmetic, 64 -> 128 -> 64 widths
+  bool mff_fusable(int C) const { return m->mff_fused && m->precision == KP2D_PREC_F16X3 && C == 64; }
+  Act mff_tail(const std::string& p, const Act& f0, int C, int h, int w, bool pool) {
+    Act f3 = alloc(C, pool ? h / 2 : h, pool ? w / 2 : w);
+    if (rc == KP2D_OK && !dry) {
+      const ConvPack& c1 = m->convs[m->conv_index.at(p + ".mff.fn.net.1.net.1")];
+      const ConvPack& c3 = m->convs[m->conv_index.at(p + ".mff.fn.net.3")];
+      MffTailArgs a{};
+      a.h = ptr(f0);
+      a.wdw = m->blob + m->vecs.at(p + ".mff.fn.net.1.net.0.weight").off;
+      a.bdw = m->blob + m->vecs.at(p + ".mff.fn.net.1.net.0.bias").off;
+      a.w1 = m->blob + c1.w16_off; a.sc1 = m->blob + c1.sc16_off; a.sh1 = m->blob + c1.sh_off;
+      a.w3 = m->blob + c3.w16_off; a.sc3 = m->blob + c3.sc16_off; a.sh3 = m->blob + c3.sh_off;
+      a.out = ptr(f3); a.B = B; a.H = h; a.W = w; a.pool = pool ? 1 : 0;
+      const double px = (double)B * h * w;
+      prof_begin(p + ".mff.fn.net.1-3", "mff_tail", px * (18.0 * 128 + 2.0 * 128 * 128 + 2.0 * 128 * 64), 4.0 * px * (128 + (pool ? 16 : 64)));
+      check(launch_mff_tail(a, stream), (p + ".mff tail").c_str());
+      prof_end();
+    }
     return f3;
   }
   // CBR -> NHWC activation (optionally pooled / pooled+full / pixel-shuffled)
@@ -1740,6 +1768,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "s16_min_items") {     // conv3x3_s16.hip (split activations through the backbone's 32-channel stage): 0 automatic, N from N tiles, -1 never
     if (value > 0x7fffffffL || value < -1) return fail(KP2D_ERR_ARG, "s16_min_items out of range");
     m->s16_min = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "mff_fused") {         // 1 (default): depthwise 3x3 -> 1x1 -> GELU -> 1x1 of the attention modules' MixFeedForward as one launch
+    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "mff_fused is 0 or 1");
+    m->mff_fused = value != 0;
     return KP2D_OK;
   }
   if (k == "stem_fusion") {       // 1 (default): big grids compute conv1a inside conv1b's launch; 0: always two launches

@@ -156,6 +156,17 @@ int launch_channel_layernorm(const LnArgs& a, hipStream_t s);
 struct DwArgs { const float* x; const float* w; const float* bias; float* y; int B, H, W, C; };   // w: [9][C]
 int launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 
+// MixFeedForward's tail fused (mff_tail.hip): depthwise 3x3 + bias -> 1x1 (128 -> 128) + bias -> GELU -> 1x1 (128 -> 64) + bias [-> MaxPool2d(2,2)]
+struct MffTailArgs {
+  const float* h;                                       // net.0's output, NHWC [B][H][W][128]
+  const float* wdw; const float* bdw;                   // depthwise weights [9][128], bias [128]
+  const float* w1; const float* sc1; const float* sh1;  // net.1.net.1: split-fp16 pack (64-channel groups), scale (2^-e), bias
+  const float* w3; const float* sc3; const float* sh3;  // net.3
+  float* out;                                           // [B][H][W][64], or pooled [B][H/2][W/2][64]
+  int B, H, W, pool;
+};
+int launch_mff_tail(const MffTailArgs& a, hipStream_t s);
+
 struct AttnArgs {
   const float* q;      // [B][S][C]   (to_q output, NHWC)
   const float* kv;     // [B][T][2C]  (to_kv output: k = channels [0,C), v = [C,2C))

@@ -1086,6 +1086,37 @@ def test_warp_specialised_multichunk_conv_equals_the_general_kernels(config, v3,
         assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()), wsm_layers)
 
 
+@pytest.mark.parametrize("config,v3,ncls,B,H,W", [("S_A", True, 19, 2, 96, 128), ("S_A", False, 28, 3, 104, 176), ("S_A", True, 19, 1, 240, 320),
+                                                  ("N_A", True, 19, 2, 64, 96)])
+def test_mixffn_tail_as_one_launch_equals_the_three_launches(config, v3, ncls, B, H, W):
+    """MixFeedForward's tail — depthwise 3x3 -> 1x1 (GELU) -> 1x1, and the max-pool behind the first module — as ONE kernel
+    (mff_tail.hip; the GELU output goes from the accumulators of one matrix product straight into the operands of the next)
+    against the three launches (mff_fused = 0): both modules' outputs (.mff taps: full-resolution and pooled) and every
+    output of the forward to 2e-5 of the tensor's range — same formulas, the matrix products group K differently.  Ragged
+    tiles (26 x 44 and 13 x 22 maps), one frame, and N_A (48-channel modules: not fusable, must simply still run)."""
+    model, _ = product_model(config, v3, ncls)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=29)).to(DEV)
+    cw = 64 if config == "S_A" else 48
+    taps = [("seg_head.convs.1.mff", (cw, H // 8, W // 8)), ("seg_head.convs.2.mff", (cw, H // 8, W // 8))]
+    with torch.no_grad():
+        model(x[:1])
+        eng = model._engine
+        assert eng.lib.kp2d_set_option(eng.handle, b"mff_fused", 0) == 0
+        ran_off = _kernels_that_ran(model, x)
+        ref = {k: v.clone() for k, v in model(x).items()}
+        ref_t = [model.forward_with_tap(x, n, shp)[1].clone() for n, shp in taps]
+        assert eng.lib.kp2d_set_option(eng.handle, b"mff_fused", 1) == 0
+        ran_on = _kernels_that_ran(model, x)
+        got = {k: v.clone() for k, v in model(x).items()}
+        got_t = [model.forward_with_tap(x, n, shp)[1].clone() for n, shp in taps]
+    assert not any("mff_tail" in k for ks in ran_off.values() for k in ks)
+    fused = [l for l, ks in ran_on.items() if any("mff_tail" in k for k in ks)]
+    assert (len(fused) == 2) == (config == "S_A"), (fused, sorted(ran_on))
+    for r, g in list(zip(ref_t, got_t)) + [(ref[k].float(), got[k].float()) for k in ref]:
+        assert r.shape == g.shape and not bool(torch.isnan(g).any())
+        assert float((r - g).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), float((r - g).abs().max())
+
+
 def _set_s16(model, value, ws_min=None):
     eng = model._engine
     assert eng.lib.kp2d_set_option(eng.handle, b"s16_min_items", value) == 0

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=1, help="batch > 1: batches in flight (pipeline.BatchStream.submit_frames); 1 = inference() per batch")
     ap.add_argument("--match", action="store_true", help="batch 1 only: match every frame against its predecessor on the device")
     ap.add_argument("--semantic", action="store_true", help="with --match: per-class matching (match_semantic)")
+    ap.add_argument("--lightglue", action="store_true", help="batch 1 only: LightGlue (config S, seeded weights) as the loop's matcher instead of brute force")
+    ap.add_argument("--top-k-matches", type=int, default=0, help="with --match / --lightglue: the loop's cap on the device (0: every match)")
     a = ap.parse_args()
     from nano_vs_slam_amd.kp2dtiny.models.kp2dtiny import tiny_factory
     from nano_vs_slam_amd.pipeline import BatchStream, FrameStream, inference
@@ -39,9 +41,29 @@ def main():
         # the VO loop: one frame per call, replayed HIP graph + overlapped upload (pipeline.FrameStream)
         if a.semantic:
             net.sample_segmentation = True
-        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0", slots=a.slots, match=a.match, semantic=a.semantic)
+        matcher = None
+        if a.lightglue:
+            from lightglue.lightglue import LightGlue
+            from lightglue.lightglue_configs import get_light_glue_config
+            from nano_vs_slam_amd.synthetic import seeded_linear_state_dict
+            matcher = LightGlue(dict(get_light_glue_config("S"), filter_threshold=0.0))
+            shapes = {k: tuple(v.shape) for k, v in matcher.state_dict().items()}
+            matcher.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_linear_state_dict(shapes).items()})
+            matcher = matcher.to("cuda:0").eval()
+        matching = a.match or a.lightglue
+        fs = FrameStream(net, (240, 320), None, 0.7, 1000, "cuda:0", slots=a.slots, match="lightglue" if a.lightglue else a.match,
+                         semantic=a.semantic, matcher=matcher, top_k_matches=a.top_k_matches)
+        # matching: consecutive frames of one scene shifted by whole cells (4 pixels) plus a little noise, as the tests' _vo_frames:
+        # most keypoints have their correspondence in the next frame and survive the ratio test (hundreds of matches per frame;
+        # round 4's frames were shifted by single pixels: 1-3 matches per frame)
         rng = np.random.default_rng(1)
-        seq = [np.roll(frames[0], (i % 5, i % 7), axis=(0, 1)) for i in range(a.steps)] if a.match else [frames[0]] * a.steps
+        if matching:
+            seq = []
+            for i in range(a.steps):
+                f = np.roll(frames[0], (4 * ((i // 2) % 6), 4 * (i % 12)), axis=(0, 1)).astype(np.int16) + rng.integers(-2, 3, frames[0].shape)
+                seq.append(np.clip(f, 0, 255).astype(np.uint8))
+        else:
+            seq = [frames[0]] * a.steps
         for _ in fs.map(seq[:5]):
             pass
         torch.cuda.synchronize()
@@ -52,8 +74,11 @@ def main():
             nm += len(r[0])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        what = ("extract + select + match against the previous frame (" + ("per class, " if a.semantic else "") + "BF k-NN(2) + ratio + "
-                "one-to-one) on the device, D2H of the matched coordinate pairs only") if a.match else "H2D of uint8 frames and D2H of keypoints"
+        how = "LightGlue (config S, padded sets: kp2d_lg_forward_counts) + get_matches_scores" if a.lightglue else \
+              (("per class, " if a.semantic else "") + "BF k-NN(2) + ratio + one-to-one")
+        cap = f", top_k_matches {a.top_k_matches}" if a.top_k_matches > 0 else ""
+        what = (f"extract + select + match against the previous frame ({how}{cap}) on the device, D2H of the matched coordinate "
+                "pairs only") if matching else "H2D of uint8 frames and D2H of keypoints"
         print(json.dumps({"metric": "frames/sec KP2DTiny-S 240x320 front-end incl. " + what,
                           "value": round(1e3 / ms, 1), "ms_per_step": round(ms, 3), "batch": 1,
                           "rows_per_frame": round(nm / n, 1),
