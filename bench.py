@@ -168,7 +168,7 @@ def cpu_baseline(args, sd_np):
 def rocprof_conv_frac(flops_per_forward, peak_tflops):
     """The conv family's roofline fraction recomputed from the newest committed rocprofv3 --stats summary of this workload
     (profiles/r<round>_kernel_stats_single_lane.csv: `KP2D_LANES=1 ... bench.py --in-flight 1` under the profiler, one lane,
-    nothing overlapped): sum of the conv3x3_f16x3* kernels' durations / forwards in that run (conv1a runs once per forward).
+    nothing overlapped): sum of the conv3x3_f16x3* kernels' durations / forwards in that run (NetVLAD's finish pass runs once per forward).
     Printed beside the HIP-event figure so that the line and the CSV cannot drift apart unnoticed."""
     import csv
     import glob
@@ -186,7 +186,7 @@ def rocprof_conv_frac(flops_per_forward, peak_tflops):
         if "conv3x3_f16x3" in name:
             conv_ns += float(row["TotalDurationNs"])
             launches += int(row["Calls"])
-        if "conv1a" in name:
+        if "netvlad_finish" in name:      # once per forward and lane (conv1a is not a launch of its own on big grids: STEM)
             fwd += int(row["Calls"])
     if not fwd or not conv_ns:
         return None

@@ -545,32 +545,11 @@ __global__ __launch_bounds__(256) void conv1a_u8_kernel(const Conv1aArgs a, cons
   const int b = bid / tiles_y;
   const int y0 = ty * 16, x0 = tx * 16;
   const unsigned char* img = frames + (size_t)b * Hs * Ws * 3;
-  const bool same = Hs == H && Ws == W;
-  const float ry = (float)Hs / (float)H, rx = (float)Ws / (float)W;
   for (int e = threadIdx.x; e < HP * HP; e += 256) {
     const int py = e / HP, px = e - py * HP;
     const int y = y0 - 1 + py, x = x0 - 1 + px;
     float v[3] = {0.f, 0.f, 0.f};                       // the convolution's zero padding (of the NORMALISED frame)
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      if (same) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = (float)img[((size_t)y * Ws + x) * 3 + c] / 255.0f;
-      } else {
-        const float sy = fmaxf(((float)y + 0.5f) * ry - 0.5f, 0.f);
-        const float sx = fmaxf(((float)x + 0.5f) * rx - 0.5f, 0.f);
-        const int ya = min((int)sy, Hs - 1), xa = min((int)sx, Ws - 1);
-        const int yb = min(ya + 1, Hs - 1), xb = min(xa + 1, Ws - 1);
-        const float wy = sy - (float)ya, wx = sx - (float)xa;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float a00 = (float)img[((size_t)ya * Ws + xa) * 3 + c] / 255.0f, a01 = (float)img[((size_t)ya * Ws + xb) * 3 + c] / 255.0f;
-          const float a10 = (float)img[((size_t)yb * Ws + xa) * 3 + c] / 255.0f, a11 = (float)img[((size_t)yb * Ws + xb) * 3 + c] / 255.0f;
-          v[c] = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = (v[c] - 0.5f) * 2.0f;
-    }
+    if (y >= 0 && y < H && x >= 0 && x < W) frame_pixel(img, Hs, Ws, H, W, y, x, v);      // conv_common.h (shared with kp2d_preprocess)
 #pragma unroll
     for (int c = 0; c < 3; ++c) s_in[(c * HP + py) * HPP + px] = v[c];
   }

@@ -409,14 +409,14 @@ __host__ __device__ constexpr int ws_trips(int ntiles, int t0, int G) { return (
 // 11k cycles per tile and the fused layer took 0.218 ms against 0.097 + 0.137 for the two launches).
 // No barrier beyond the tile's own: the window is wave-private and a wave's LDS instructions execute in order.
 // Arithmetic: split-fp16 products like every other layer of this precision mode (x = xh + xl, w 2^e = wh + wl, fp32
-// accumulate: ~1e-7 relative to the exact fp32 FMA chain of conv1a_kernel) — NOT the bits of the stand-alone conv1a launch,
-// which small grids keep: results of a forward are bit-identical within a schedule (lane count, steps in flight), and agree
-// to fp32 rounding between the fused and the unfused first layer (kp2d_set_option("stem_fusion", 0) turns it off).
+// accumulate: ~1e-7 relative to the exact fp32 FMA chain of round 4's conv1a_kernel).  conv1a's own launch in this mode
+// (conv1a_mfma_kernel below: small grids, sub-batches, uint8 frames) issues the SAME products in the same order, so fused and
+// unfused first layers agree bit for bit and a forward's results do not depend on which one a grid size picks.
 struct StemArgs {
   const float* x;                     // [B,3,H,W] frames
   const float* w;                     // conv1a weights [27][16] (k = ci 9 + dy 3 + dx)
   const float* scale; const float* shift;   // BatchNorm folded, [16]
-  float wscale, wunscale;             // 2^e, 2^-e: the weights are split as w 2^e (lo halves stay normal)
+  const float* wsc;                   // device pointer to 2^e: the weights are split as w 2^e (lo halves stay normal); part of the weight blob
   int act;
 };
 namespace {
@@ -505,19 +505,20 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
       for (int e = lane; e < 2 * ST_XPL / 16; e += 64) *reinterpret_cast<float4*>(xw + 16 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
       // weights of output channel slp: k-group slg holds taps 2 slg, 2 slg + 1 (MFMA 0) / tap 8 in k-group 0 (MFMA 1), 4 halves per
       // tap = channels (0, 1, 2, padding)
+      const float wscale = st.wsc[0];                 // a power of two: 1 / wscale is exact
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
           const int tap = j == 0 ? 2 * slg + (hh >> 2) : 8, ci = hh & 3;
           const bool on = ci < 3 && (j == 0 || (slg == 0 && hh < 4));
-          const float wv = on ? st.w[(ci * 9 + tap) * 16 + slp] * st.wscale : 0.f;
+          const float wv = on ? st.w[(ci * 9 + tap) * 16 + slp] * wscale : 0.f;
           const _Float16 h = (_Float16)wv;
           swh[j][hh] = h;
           swl[j][hh] = (_Float16)(wv - (float)h);
         }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ssc[i] = st.scale[4 * slg + i] * st.wunscale; ssh[i] = st.shift[4 * slg + i]; }
+      for (int i = 0; i < 4; ++i) { ssc[i] = st.scale[4 * slg + i] * (1.f / wscale); ssh[i] = st.shift[4 * slg + i]; }
       auto toff = [](int t) { return ((t / 3) * ST_XC + (t % 3)) * 8; };
       so0 = toff(2 * slg);
       so1 = toff(2 * slg + 1);
@@ -841,6 +842,128 @@ __global__ __launch_bounds__(768, 3) void conv3x3_f16x3_ws_kernel(const ConvArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backbone.conv1a as its own launch in the split-fp16 arithmetic — the SAME products, in the same MFMA sequence with the same
+// operand layout, as the STEM staging code above: an output value depends on its pixel's 27 inputs and the weights only, so
+// this kernel and the fused form agree bit for bit, and a forward's results do not depend on which of the two a grid size,
+// a sub-batch split or a lane count picks (tests/test_gpu_parity.py::test_full_size_properties).  Small grids, sub-batches
+// below the warp-specialised form's tile count, and uint8 frames (U8: /255, the bilinear resize and .sub(0.5).mul(2) of
+// kp2d_preprocess computed while the window is filled — conv3x3.hip conv1a_u8_kernel's arithmetic) take this kernel.
+// A wave = one row x 64 pixels (four M-tiles); its 3 x 72 window [row][x][c0 c1 c2 0] hi / lo lives in its own LDS block.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int C1_CW = 72, C1_PL = 3 * C1_CW * 8;       // window columns (x0 - 4 .. x0 + 67); one plane (1,728 B)
+}
+template <bool U8>
+__global__ __launch_bounds__(256) void conv1a_mfma_kernel(const Conv1aArgs a, const StemArgs st, const unsigned char* __restrict__ frames,
+                                                          const int Hs, const int Ws) {
+  __shared__ __attribute__((aligned(16))) char s_win[4 * 2 * C1_PL];
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL (as every split kernel)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slg = lane >> 4, slp = lane & 15;
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + 63) >> 6, tiles_y = (H + 3) >> 2;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y = ty * 4 + wave, x0 = tx * 64;
+  char* const xw = s_win + wave * 2 * C1_PL;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = 0x7ffffff0;
+  // weights / BatchNorm: exactly the STEM set-up
+  f16x8 swh[2], swl[2];
+  float ssc[4], ssh[4];
+  const float wscale = st.wsc[0];                     // a power of two: 1 / wscale is exact
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+      const int tap = j == 0 ? 2 * slg + (hh >> 2) : 8, ci = hh & 3;
+      const bool on = ci < 3 && (j == 0 || (slg == 0 && hh < 4));
+      const float wv = on ? st.w[(ci * 9 + tap) * 16 + slp] * wscale : 0.f;
+      const _Float16 h = (_Float16)wv;
+      swh[j][hh] = h;
+      swl[j][hh] = (_Float16)(wv - (float)h);
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ssc[i] = st.scale[4 * slg + i] * (1.f / wscale); ssh[i] = st.shift[4 * slg + i]; }
+  // window: slot e = (row e / 18, column quad e % 18), three planes
+  if (lane < 54) {
+    const int wr = lane / 18, q = lane - 18 * wr;
+    const int gy = y - 1 + wr, gx = x0 - 4 + 4 * q;
+    float c0[4], c1[4], c2[4];
+    if constexpr (!U8) {
+      const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.x), 0, (int)((long)a.B * 3 * H * W * 4), 0x00020000);
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;      // (W is a multiple of 8: whole float4s)
+      const int off = ok ? ((b * 3 * H + gy) * W + gx) * 4 : OOB;
+      const float4 v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      const float4 v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, H * W * 4, 0));
+      const float4 v2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 2 * H * W * 4, 0));
+      c0[0] = v0.x; c0[1] = v0.y; c0[2] = v0.z; c0[3] = v0.w;
+      c1[0] = v1.x; c1[1] = v1.y; c1[2] = v1.z; c1[3] = v1.w;
+      c2[0] = v2.x; c2[1] = v2.y; c2[2] = v2.z; c2[3] = v2.w;
+    } else {
+      const unsigned char* img = frames + (size_t)b * Hs * Ws * 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int xx = gx + i;
+        float v[3] = {0.f, 0.f, 0.f};                     // the convolution's zero padding (of the NORMALISED frame)
+        if (gy >= 0 && gy < H && xx >= 0 && xx < W) frame_pixel(img, Hs, Ws, H, W, gy, xx, v);      // conv_common.h (shared with kp2d_preprocess)
+        c0[i] = v[0]; c1[i] = v[1]; c2[i] = v[2];
+      }
+    }
+    char* const d = xw + (wr * C1_CW + 4 * q) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2 ha, la, hb, lb;
+      split2(c0[i], c1[i], ha, la);
+      split2(c2[i], 0.f, hb, lb);
+      *reinterpret_cast<h4*>(d + 8 * i) = h4{ha[0], ha[1], hb[0], hb[1]};
+      *reinterpret_cast<h4*>(d + 8 * i + C1_PL) = h4{la[0], la[1], lb[0], lb[1]};
+    }
+  }
+  asm volatile("" ::: "memory");                     // (wave-private window: in-order LDS; the compiler must keep the order too)
+  auto toff = [](int t) { return ((t / 3) * C1_CW + (t % 3)) * 8; };
+  const int so0 = toff(2 * slg), so1 = toff(2 * slg + 1);
+  const float slope1 = st.act == ACT_LEAKY ? 0.01f : (st.act == ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const char* const ph = xw + (16 * mt + slp + 3) * 8;      // window pixel of tap (0, 0): column x - 1 = window column x - x0 + 3
+    const h4 a0 = *reinterpret_cast<const h4*>(ph + so0), a1 = *reinterpret_cast<const h4*>(ph + so1);
+    const h4 b0 = *reinterpret_cast<const h4*>(ph + so0 + C1_PL), b1 = *reinterpret_cast<const h4*>(ph + so1 + C1_PL);
+    const h4 a8 = *reinterpret_cast<const h4*>(ph + toff(8)), b8 = *reinterpret_cast<const h4*>(ph + toff(8) + C1_PL);
+    const f16x8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const f16x8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    const f16x8 yh = {a8[0], a8[1], a8[2], a8[3], 0, 0, 0, 0};
+    const f16x8 yl = {b8[0], b8[1], b8[2], b8[3], 0, 0, 0, 0};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};                // (the STEM sequence, term for term)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[1], yh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[0], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[1], yh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[0], xh, acc, 0, 0, 0);
+    const int x = x0 + 16 * mt + slp;
+    float4 v;
+    { const float tt = fmaf(acc[0], ssc[0], ssh[0]); v.x = fmaxf(tt, tt * slope1); }
+    { const float tt = fmaf(acc[1], ssc[1], ssh[1]); v.y = fmaxf(tt, tt * slope1); }
+    { const float tt = fmaf(acc[2], ssc[2], ssh[2]); v.z = fmaxf(tt, tt * slope1); }
+    { const float tt = fmaf(acc[3], ssc[3], ssh[3]); v.w = fmaxf(tt, tt * slope1); }
+    if (y < H && x < W) reinterpret_cast<float4*>(a.out + (((size_t)b * H + y) * W + x) * 16)[slg] = v;
+  }
+}
+
+int launch_conv1a_mfma(const Conv1aArgs& a, const float* wscale_dev, const unsigned char* frames, int Hs, int Ws, hipStream_t s) {
+  if (a.cout != 16 || a.cin != 3 || (a.W & 7)) return -1001;
+  if ((long)a.B * 3 * a.H * a.W * 4 >= 0x7ffffff0L) return -1002;
+  const StemArgs st{a.x, a.w, a.scale, a.shift, wscale_dev, a.act};
+  const int grid = ((a.W + 63) >> 6) * ((a.H + 3) >> 2) * a.B;
+  if (frames) hipLaunchKernelGGL(conv1a_mfma_kernel<true>, dim3(grid), dim3(256), 0, s, a, st, frames, Hs, Ws);
+  else hipLaunchKernelGGL(conv1a_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, a, st, frames, Hs, Ws);
+  return (int)hipGetLastError();
+}
+
 template <bool S16OUT, bool STEM>
 static int launch_ws_t(const ConvArgs& a0, const StemArgs& st, hipStream_t s) {
   ConvArgs a = a0;
@@ -863,7 +986,7 @@ static int launch_ws_t(const ConvArgs& a0, const StemArgs& st, hipStream_t s) {
 template <bool S16OUT>
 static int launch_ws(const ConvArgs& a, hipStream_t s) {
   if (a.stem_x) {      // conv1a computed by the staging waves (kp2d_api.cpp hands its arguments over instead of launching it)
-    const StemArgs st{a.stem_x, a.stem_w, a.stem_scale, a.stem_shift, a.stem_wscale, 1.f / a.stem_wscale, a.stem_act};
+    const StemArgs st{a.stem_x, a.stem_w, a.stem_scale, a.stem_shift, a.stem_wscale, a.stem_act};
     return launch_ws_t<S16OUT, true>(a, st, s);
   }
   return launch_ws_t<S16OUT, false>(a, StemArgs{}, s);

@@ -47,6 +47,34 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// One pixel of the frame front-end (src/evaluation/visual_odometry.py:77-87: kornia.image_to_tensor / 255, kornia bilinear
+// resize with align_corners=False, .sub(0.5).mul(2)) from uint8 HWC frames: ONE definition for the three kernels that compute
+// it (post.hip preprocess_kernel, conv3x3.hip conv1a_u8_kernel, conv3x3_f16.hip conv1a_mfma_kernel<true>), with floating-point
+// contraction off — left to the compiler, the same source line was fused into FMAs in one kernel and not in another, and
+// "forward_frames(frames) == forward(preprocess(frames))" held by luck.
+__device__ __forceinline__ void frame_pixel(const unsigned char* __restrict__ img, int Hs, int Ws, int H, int W, int y, int x, float v[3]) {
+#pragma clang fp contract(off)
+  if (Hs == H && Ws == W) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (float)img[((size_t)y * Ws + x) * 3 + c] / 255.0f;
+  } else {
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)Hs / (float)H) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)Ws / (float)W) - 0.5f, 0.f);
+    const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
+    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+    const float wy = sy - (float)y0, wx = sx - (float)x0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a00 = (float)img[((size_t)y0 * Ws + x0) * 3 + c] / 255.0f, a01 = (float)img[((size_t)y0 * Ws + x1) * 3 + c] / 255.0f;
+      const float a10 = (float)img[((size_t)y1 * Ws + x0) * 3 + c] / 255.0f, a11 = (float)img[((size_t)y1 * Ws + x1) * 3 + c] / 255.0f;
+      const float top = (1.f - wx) * a00 + wx * a01, bot = (1.f - wx) * a10 + wx * a11;
+      v[c] = (1.f - wy) * top + wy * bot;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = (v[c] - 0.5f) * 2.0f;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));

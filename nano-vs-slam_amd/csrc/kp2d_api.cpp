@@ -149,8 +149,11 @@ struct kp2d_model {
   int wsm_tr = 0;         // kp2d_set_option("wsm_transposed")
   int wsm_min = 0;        // kp2d_set_option("wsm_min_items"): 0 = automatic (KP2D_WSM, else one item per workgroup), < 0 = never (conv3x3_wsm.hip)
   bool mff_fused = !(getenv("KP2D_MFF") && getenv("KP2D_MFF")[0] == '0');   // kp2d_set_option("mff_fused"): MixFeedForward's tail as one launch (mff_tail.hip)
-  bool stem_fusion = !(getenv("KP2D_STEM") && getenv("KP2D_STEM")[0] == '0');    // kp2d_set_option("stem_fusion") (KP2D_STEM=0: the A/B default): conv1a computed inside conv1b's launch on big grids (conv3x3_f16.hip STEM)
-  float conv1a_wscale = 1.f;  // 2^e of the split of conv1a's weights (pack())
+  // kp2d_set_option("stem_fusion") / KP2D_STEM: the first layer — 1 (default): split-fp16 products, computed inside conv1b's launch on
+  // big grids (conv3x3_f16.hip STEM) and by conv1a_mfma_kernel otherwise (the same bits); 2: the same arithmetic, never fused; 0: round 4's
+  // exact-fp32 FMA kernels (conv1a_kernel / conv1a_u8_kernel)
+  int stem_fusion = getenv("KP2D_STEM") ? std::max(0, std::min(2, atoi(getenv("KP2D_STEM")))) : 1;
+  size_t conv1a_ws = 0;       // blob offset of 2^e, the scale conv1a's weights are split at (pack(); in the blob, so that it travels with an RCCL weight broadcast)
   bool multi_launch = true;   // kp2d_set_option("multi_launch"): independent layers of a level as one launch on small grids
   int s16_min = 0;        // kp2d_set_option("s16_min_items"): conv3x3_s16.hip — 0 = automatic (three rounds of tiles per workgroup), N = from N tiles, < 0 = never
   int precision = KP2D_PREC_F16X3;
@@ -371,6 +374,7 @@ int describe(kp2d_model* m) {
   m->conv1a_w = take((size_t)9 * g.in_channels * c1);
   m->conv1a_sc = take(c1);
   m->conv1a_sh = take(c1);
+  m->conv1a_ws = take(1);
   for (auto& c : m->convs) {
     if (c.cin % 4) return fail(KP2D_ERR_UNSUPPORTED, "%s: input channels %d not a multiple of 4", c.name.c_str(), c.cin);
     if (c.shuffle && (c.cout % 16)) return fail(KP2D_ERR_UNSUPPORTED, "%s: pixel-shuffle conv needs cout %% 16 == 0", c.name.c_str());
@@ -428,7 +432,7 @@ int pack(kp2d_model* m, std::vector<float>& blob) {
     for (float v : w) wmax = std::max(wmax, std::fabs(v));
     int e16 = 11;
     while (e16 > -96 && wmax * std::ldexp(1.0f, e16) > 32768.0f) --e16;
-    m->conv1a_wscale = std::ldexp(1.0f, e16);
+    blob[m->conv1a_ws] = std::ldexp(1.0f, e16);
   }
   for (const auto& c : m->convs) {
     std::vector<float> wvirt;
@@ -705,7 +709,7 @@ struct Plan {
     a.s16_min = m->s16_min;
     if (stem_x && name == "backbone.conv1b") {
       a.stem_x = stem_x; a.stem_w = m->blob + m->conv1a_w; a.stem_scale = m->blob + m->conv1a_sc; a.stem_shift = m->blob + m->conv1a_sh;
-      a.stem_wscale = m->conv1a_wscale; a.stem_act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
+      a.stem_wscale = m->blob + m->conv1a_ws; a.stem_act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
     }
     a.w = m->blob + (split ? c.w16_off : c.w_off);
     a.w_tr = (split && c.w16t_off) ? m->blob + c.w16t_off : nullptr;
@@ -951,8 +955,11 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // Big grids: conv1a inside conv1b's launch (conv3x3_f16.hip STEM) — its output, the largest tensor of the forward after
   // `skip`, is never written.  Float frames, RGB, 16 -> 32 first stage, split-fp16 arithmetic, a pooled conv1b on the
   // warp-specialised form; a tap on conv1a keeps the two launches (the fused layer has no output to copy).
-  const bool stem = m->stem_fusion && m->precision == KP2D_PREC_F16X3 && !o.frames && g.in_channels == 3 && m->c1 == 16 && m->c2 == 32 &&
-                    g.downsample >= 2 && conv3x3_ws_would_run(B, H, W, m->ws_min) && !(m->tap_dst && m->tap_name == "backbone.conv1a");
+  // The first layer in the split-fp16 arithmetic (RGB frames, 16 channels): one set of bits whether it runs fused, as its own
+  // launch, or straight from uint8 frames — so a forward's results do not depend on the grid size that picks the form.
+  const bool c1a_split = m->stem_fusion != 0 && m->precision == KP2D_PREC_F16X3 && g.in_channels == 3 && m->c1 == 16;
+  const bool stem = c1a_split && m->stem_fusion == 1 && !o.frames && m->c2 == 32 && g.downsample >= 2 && conv3x3_ws_would_run(B, H, W, m->ws_min) &&
+                    !(m->tap_dst && m->tap_name == "backbone.conv1a");
   Act t1a = P.alloc(m->c1, H, W);      // (allocated either way: the workspace size must not depend on the input kind or on a tap)
   if (stem) P.stem_x = o.x;
   if (!stem && !P.dry && P.rc == KP2D_OK) {
@@ -960,7 +967,11 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     a.x = o.x; a.w = m->blob + m->conv1a_w; a.scale = m->blob + m->conv1a_sc; a.shift = m->blob + m->conv1a_sh;
     a.out = P.ptr(t1a); a.B = B; a.H = H; a.W = W; a.cout = m->c1; a.act = lk; a.cin = g.in_channels;
     const double px = (double)B * H * W;
-    if (o.frames) {
+    if (c1a_split) {
+      P.prof_begin("backbone.conv1a", o.frames ? "conv1a_mfma_u8" : "conv1a_mfma", 2.0 * 27 * m->c1 * px,
+                   (o.frames ? 3.0 * B * o.Hs * o.Ws : 12.0 * px) + 4.0 * px * m->c1);
+      P.check(launch_conv1a_mfma(a, m->blob + m->conv1a_ws, o.frames, o.Hs, o.Ws, P.stream), "backbone.conv1a (split-fp16)");
+    } else if (o.frames) {
       P.prof_begin("backbone.conv1a", "conv1a_u8", 2.0 * 27 * m->c1 * px, 3.0 * B * o.Hs * o.Ws + 4.0 * px * m->c1);
       P.check(launch_conv1a_u8(a, o.frames, o.Hs, o.Ws, P.stream), "backbone.conv1a (uint8 frames)");
     } else {
@@ -1775,9 +1786,9 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
     m->mff_fused = value != 0;
     return KP2D_OK;
   }
-  if (k == "stem_fusion") {       // 1 (default): big grids compute conv1a inside conv1b's launch; 0: always two launches
-    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "stem_fusion is 0 or 1");
-    m->stem_fusion = value != 0;
+  if (k == "stem_fusion") {       // 1 (default): conv1a in split-fp16 products, inside conv1b's launch on big grids; 2: never fused; 0: exact-fp32 FMA kernels
+    if (value < 0 || value > 2) return fail(KP2D_ERR_ARG, "stem_fusion is 0, 1 or 2");
+    m->stem_fusion = (int)value;
     return KP2D_OK;
   }
   if (k == "multi_launch") {      // 1 (default): layers of different heads that wait for the same predecessor run as one launch on small grids

@@ -60,7 +60,7 @@ struct ConvArgs {
   int wsm_grid;                       // most workgroups of that form per launch; 0: KP2D_WSM_GRID or one per CU
   // conv1b's warp-specialised form with conv1a computed by its staging waves (conv3x3_f16.hip STEM): the frames [B,3,H,W] and
   // conv1a's weights [27][16] / folded BatchNorm; in0 is then unused.  nullptr: conv1a is its own launch
-  const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_shift; float stem_wscale; int stem_act;
+  const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_shift; const float* stem_wscale; int stem_act;   // stem_wscale: device pointer to 2^e
   int s16_min;                        // conv3x3_s16.hip: least work items for the form (0: automatic, three rounds per workgroup)
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
@@ -80,6 +80,8 @@ const char* conv3x3_last_variant();
 void conv3x3_note_variant(const char* v);
 int launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 int launch_conv1a_u8(const Conv1aArgs& a, const unsigned char* frames, int Hs, int Ws, hipStream_t s);   // frame front-end fused in
+// conv3x3_f16.hip: conv1a in the split-fp16 arithmetic of the fused first layer (STEM), bit-identical to it; frames != null: uint8 frames in
+int launch_conv1a_mfma(const Conv1aArgs& a, const float* wscale_dev, const unsigned char* frames, int Hs, int Ws, hipStream_t s);
 int launch_head3x3_pair(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s);   // a 1-channel and a 2-channel head, one launch
 int launch_head3x3(const ConvArgs& a, hipStream_t s);         // head3x3.hip: taps = 9, cout <= 4, planar outputs (exact fp32 dot products)
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s);   // conv3x3_f16.hip: taps = 9, prec = 1 (16x16x32 MFMA)

@@ -12,7 +12,7 @@
 // intrinsics so hipcc's default fp-contraction cannot fuse it differently from the reference.
 #include <cstdlib>
 
-#include "kp2d_kernels.h"
+#include "conv_common.h"
 #include "device_guard.h"
 
 namespace kp2d {
@@ -593,24 +593,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* sr
   const int y = p / W, x = p - y * W;
   const unsigned char* img = src + (size_t)b * Hs * Ws * 3;
   float v[3];
-  if (Hs == H && Ws == W) {
+  frame_pixel(img, Hs, Ws, H, W, y, x, v);             // conv_common.h: /255, bilinear resize, .sub(0.5).mul(2)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = (float)img[((size_t)y * Ws + x) * 3 + c] / 255.0f;
-  } else {
-    const float sy = fmaxf(((float)y + 0.5f) * ((float)Hs / (float)H) - 0.5f, 0.f);
-    const float sx = fmaxf(((float)x + 0.5f) * ((float)Ws / (float)W) - 0.5f, 0.f);
-    const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
-    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
-    const float wy = sy - (float)y0, wx = sx - (float)x0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float a00 = (float)img[((size_t)y0 * Ws + x0) * 3 + c] / 255.0f, a01 = (float)img[((size_t)y0 * Ws + x1) * 3 + c] / 255.0f;
-      const float a10 = (float)img[((size_t)y1 * Ws + x0) * 3 + c] / 255.0f, a11 = (float)img[((size_t)y1 * Ws + x1) * 3 + c] / 255.0f;
-      v[c] = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) dst[((size_t)b * 3 + c) * H * W + p] = (v[c] - 0.5f) * 2.0f;
+  for (int c = 0; c < 3; ++c) dst[((size_t)b * 3 + c) * H * W + p] = v[c];
 }
 
 int launch_preprocess(const unsigned char* src, float* dst, int B, int Hs, int Ws, int H, int W, hipStream_t s) {

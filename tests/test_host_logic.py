@@ -260,3 +260,51 @@ def test_no_wide_buffer_store_carries_its_offset_in_an_sgpr(tmp_path):
                 print("SGPR soffset:", ln.strip())
     assert stores > 300, stores                                   # the conv epilogues alone hold several hundred
     assert bad == 0, f"{bad} of {stores} wide buffer stores carry an SGPR soffset"
+
+
+def test_lds_dma_kernels_compile_without_spills_and_keep_their_copies_in_flight_across_barriers(tmp_path):
+    """conv3x3_s16.hip and mff_tail.hip keep LDS-DMA copies in flight ACROSS workgroup barriers (two steps / slices ahead): that rests on
+    (1) bare s_barrier instructions behind a COUNTED s_waitcnt — a `__syncthreads()` there makes hipcc drain vmcnt to 0 because
+        of the fence it carries, and the pipeline silently degrades to one step ahead (seen while writing the kernel);
+    (2) no VGPR spills (scratch traffic would join the vmcnt queue the counted waits count).
+    Cross-compiles both files for gfx950 (no GPU needed) and reads the assembly."""
+    import re
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    csrc = os.path.join(ROOT, "nano-vs-slam_amd", "csrc")
+
+    def asm_of(name):
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I" + csrc,
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(csrc, name), "-o", str(out)],
+                       check=True, capture_output=True, timeout=900)
+        return out.read_text()
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        s16, mff = ex.map(asm_of, ["conv3x3_s16.hip", "mff_tail.hip"])
+    for asm, nk, vmax in ((s16, 5, 168), (mff, 1, 256)):
+        spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
+        vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", asm)]
+        assert len(spills) == nk and all(v == 0 for v in spills), spills
+        assert all(v <= vmax for v in vgprs), vgprs
+
+    def waits_before_barriers(body):
+        lines = [ln.strip() for ln in body.splitlines()]
+        out = []
+        for i, ln in enumerate(lines):
+            if ln.startswith("s_barrier"):
+                back = [x for x in lines[max(0, i - 8):i] if x.startswith("s_waitcnt")]
+                out.append(back[-1] if back else "")
+        return out
+
+    # conv3x3_s16.hip, 32-channel items (three image stages): the DMA loop's barrier stands behind vmcnt(11), not vmcnt(0)
+    body = next(b for b in s16.split("s_endpgm") if "conv3x3_f16x3_s16_kernelILi5ELi2E" in b)
+    w = waits_before_barriers(body)
+    assert any(x.startswith("s_waitcnt vmcnt(11)") for x in w), w
+    # mff_tail.hip: every barrier of the slice loop behind vmcnt(3) lgkmcnt(0) (or the drain of the last slices), never a plain fence
+    w = waits_before_barriers(mff)
+    assert sum(1 for x in w if "vmcnt(3)" in x and "lgkmcnt(0)" in x) >= 2, w

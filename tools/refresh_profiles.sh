@@ -31,13 +31,19 @@ sweep --config N
 sweep --batch 1 --steps 300 --in-flight 1      # (a latency figure: one frame at a time)
 sweep --precision fp32
 step "LightGlue"
-timeout -k 10 200 python3 tools/bench_lightglue.py --steps 100 --warmup 10 2>"$(errf)" | tail -1 > "$OUT/lightglue.jsonl"
+timeout -k 10 300 python3 tools/bench_lightglue.py --sweep 8,16,32 --steps 60 --warmup 10 2>"$(errf)" | grep '^{' > "$OUT/lightglue.jsonl"
 timeout -k 10 200 python3 tools/bench_lightglue.py --pairs 1 --steps 200 --warmup 20 2>"$(errf)" | tail -1 >> "$OUT/lightglue.jsonl"
 cut -c1-200 "$OUT/lightglue.jsonl"
 step "PCIe-inclusive front-end"
 timeout -k 10 200 python3 tools/bench_frontend.py 2>"$(errf)" | tail -1 > "$OUT/frontend.jsonl"
 timeout -k 10 200 python3 tools/bench_frontend.py --pinned 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --pinned --in-flight 2 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --pinned --in-flight 3 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 --match 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 --match --top-k-matches 200 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 --match --semantic 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
+timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 1000 --lightglue --top-k-matches 200 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 cut -c1-200 "$OUT/frontend.jsonl"
 step "rocprofv3 kernel stats, the default bench command (two steps in flight: kernels of the two streams overlap, durations are wall time under sharing)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats2.log" 2>&1
@@ -45,9 +51,12 @@ step "rocprofv3 kernel stats, one step at a time on a single lane (nothing overl
 KP2D_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes --in-flight 1 > "$OUT/stats1.log" 2>&1
 find "$OUT/stats1" "$OUT/stats2" -name "*kernel_trace.csv" -delete      # only the --stats summaries are kept
 
-step "per-layer table"
+step "per-layer tables"
 timeout -k 10 200 python3 tools/layer_profile.py > "$OUT/layers.txt" 2>"$(errf)"
 head -3 "$OUT/layers.txt"
+timeout -k 10 200 python3 tools/layer_profile.py --batch 32 > "$OUT/layers_32frames.txt" 2>"$(errf)"
+timeout -k 10 200 python3 tools/layer_profile.py --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32 > "$OUT/layers_cfg4.txt" 2>"$(errf)"
+timeout -k 10 200 python3 tools/layer_profile.py --batch 1 --reps 20 > "$OUT/layers_1frame.txt" 2>"$(errf)"
 
 step "PMC passes"
 tools/pmc_collect.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
