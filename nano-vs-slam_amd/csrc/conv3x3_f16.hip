@@ -1073,9 +1073,14 @@ void conv3x3_note_variant(const char* v) { g_variant = v; }
 
 int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.taps != 9 || a.prec != 1) return -1000;
-  // S16P tensors (kp2d_kernels.h): read only by conv3x3_s16.hip, written by it and by the conv1b form below
-  if (a.in0.fmt == 1) return launch_conv3x3_f16x3_s16(a, s);
-  if (a.store == ST_S16P) return -1006;
+  // S16P tensors (kp2d_kernels.h): read by conv3x3_s16.hip (32 input channels) and by conv3x3_wsm.hip's IN16 form, written by
+  // both and by the conv1b form below.  No other kernel takes the layout: -1006 is a plan bug
+  if (a.in0.fmt == 1 && a.cin == 32 && a.in1.c == 0) return launch_conv3x3_f16x3_s16(a, s);
+  if (a.wsm_force) {
+    const int e = launch_conv3x3_f16x3_wsm(a, s, 64);
+    return e == -1000 ? -1006 : e;
+  }
+  if (a.in0.fmt == 1 || a.in1.fmt == 1 || a.store == ST_S16P || a.store == ST_S16P_BOTH || a.store == ST_S16P_SHUFFLE || a.store == ST_MIX16) return -1006;
   if (a.store == ST_S16P_POOL) {
     if (!(a.cin == 16 && a.in0.c == 16 && a.in1.c == 0 && a.npad == 32 && a.cout == 32 && a.act <= ACT_RELU &&
           a.in0.rs == (long)a.W * a.in0.ps && a.in0.ps == 16 && a.in0.o == 0 && conv3x3_ws_would_run(a.B, a.H, a.W, a.ws_min))) return -1006;

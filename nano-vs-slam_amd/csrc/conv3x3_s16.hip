@@ -66,7 +66,8 @@ struct S16Item { int b, y0, x0; };
 template <int STORE, int NN>
 __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const ConvArgs a, const int nitems) {
   constexpr int D_N = 16 * NN, D_WL = d_wl(D_N), D_WSLAB = d_wslab(D_N), D_NIMG = d_nimg(D_N), D_WB = d_wbase(D_N), D_SS = d_ss(D_N);
-  static_assert((STORE == ST_S16P) == (NN == 2), "S16P output: 32-channel items; fp32 outputs: 64-channel items");
+  static_assert(STORE == ST_S16P ? NN == 2 : NN == 4, "32 output channels: S16P only; 64: fp32 forms or S16P full + pooled");
+  constexpr bool S16OUT = STORE == ST_S16P || STORE == ST_S16P_BOTH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
   for (int gi = tid; gi < D_NCH * 9 * D_N * 4; gi += D_THREADS) {
     const int row = gi >> 2, quad = gi & 3;          // quads 0, 1: the 16 hi halves; 2, 3: the 16 lo halves
     const int n = row % D_N, cs = row / D_N;         // cs = chunk * 9 + slot
-    const int np = STORE == ST_S16P ? (16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3)) : n;
+    const int np = S16OUT ? (32 * (n >> 5) + 16 * ((n >> 2) & 1) + 4 * ((n >> 3) & 3) + (n & 3)) : n;      // (N-tile PAIRS interleaved)
     const int chunk = cs / 9, slot = cs - 9 * chunk;
     *reinterpret_cast<float4*>(sm + D_WB + chunk * D_WSLAB + (quad >> 1) * D_WL + (slot * D_N + np) * 32 + (quad & 1) * 16) =
         reinterpret_cast<const float4*>(a.w)[gi];
@@ -289,22 +290,15 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
   };
   auto finish = [&](const S16Item& it) {
     const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
-    if constexpr (store == ST_S16P) {
-      // lane group lg holds channels 8 lg .. 8 lg + 7 of its pixel (tiles n = 0, 1): chunk lg >> 1, halves 8 (lg & 1) .. + 7
+    if constexpr (S16OUT) {
+      // per N-tile pair p: lane group lg holds channels 32 p + 8 lg .. + 7 of its pixel (tiles 2 p, 2 p + 1): chunk
+      // 2 p + (lg >> 1), halves 8 (lg & 1) .. + 7.  ST_S16P_BOTH (conv3b): also the 2 x 2 maximum, as a second S16P tensor
+      constexpr bool both = store == ST_S16P_BOTH;
       const int obs = H * W * a.cout;                                     // output frame stride, floats (= bytes / 4)
+      const int obp = Hp * Wp * a.cout;
       const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.out0 + (size_t)it.b * obs, 0, obs * 4, 0x00020000);
-      const int cpart = (lg >> 1) * (H * 2 * W * 32) + (lg & 1) * 16;
-      const int cinv = 8 * lg < a.cout ? 0 : OOB;                         // chunks past cout (a multiple of 16)
-      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sm + D_SS + (8 * lg) * 4);
-      const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sm + D_SS + (8 * lg + 4) * 4);
-      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(sm + D_SS + (D_MAXC + 8 * lg) * 4);
-      const f32x4 sh1 = *reinterpret_cast<const f32x4*>(sm + D_SS + (D_MAXC + 8 * lg + 4) * 4);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
-        const int inv = ((y < H && x < W) ? 0 : OOB) | cinv;
-        const int o = (y * 2 * W + x) * 32 + cpart;
-        const f32x4 v0 = affine(acc[m][0], sc0, sh0), v1 = affine(acc[m][1], sc1, sh1);
+      const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.out1 + (size_t)it.b * obp, 0, both ? obp * 4 : 0, 0x00020000);
+      auto split_store = [&](const f32x4 v0, const f32x4 v1, const __amdgpu_buffer_rsrc_t rs, int o, int lo_off, int inv) {
         f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
         split2(v0[0], v0[1], h0, l0);
         split2(v0[2], v0[3], h1, l1);
@@ -312,8 +306,47 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
         split2(v1[2], v1[3], h3, l3);
         const i32x4 hi = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
         const i32x4 lo = {__builtin_bit_cast(int, l0), __builtin_bit_cast(int, l1), __builtin_bit_cast(int, l2), __builtin_bit_cast(int, l3)};
-        __builtin_amdgcn_raw_buffer_store_b128(hi, rs0, KP2D_DBG_ON(64) ? OOB : (o | inv), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lo, rs0, KP2D_DBG_ON(64) ? OOB : ((o + W * 32) | inv), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rs, KP2D_DBG_ON(64) ? OOB : (o | inv), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rs, KP2D_DBG_ON(64) ? OOB : ((o + lo_off) | inv), 0, 0);
+      };
+      auto quad_max = [&](const f32x4 v) -> f32x4 {                       // maximum over lanes 4 q .. 4 q + 3 (conv3x3_wsm.hip)
+        f32x4 p;
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        return p;
+      };
+#pragma unroll
+      for (int pr = 0; pr < NN / 2; ++pr) {
+        const int cl = 32 * pr + 8 * lg;                                  // this lane's first channel
+        if (32 * pr >= a.cout) continue;
+        const int cinv = cl < a.cout ? 0 : OOB;                           // chunks past cout (a multiple of 16)
+        const int cpart = (cl >> 4) * (H * 2 * W * 32) + (lg & 1) * 16;
+        const int ppart = (cl >> 4) * (Hp * 2 * Wp * 32) + (lg & 1) * 16;
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sm + D_SS + cl * 4);
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sm + D_SS + (cl + 4) * 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(sm + D_SS + (D_MAXC + cl) * 4);
+        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(sm + D_SS + (D_MAXC + cl + 4) * 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
+          const int inv = ((y < H && x < W) ? 0 : OOB) | cinv;
+          const f32x4 v0 = affine(acc[m][2 * pr], sc0, sh0), v1 = affine(acc[m][2 * pr + 1], sc1, sh1);
+          split_store(v0, v1, rs0, (y * 2 * W + x) * 32 + cpart, W * 32, inv);
+          if constexpr (both) {
+            const int yp = y >> 1, xp = x >> 1;
+            const int invp = (((lp & 3) == 0 && yp < Hp && xp < Wp) ? 0 : OOB) | cinv;      // lane 4 q stores the quad's maximum
+            split_store(quad_max(v0), quad_max(v1), rs1, (yp * 2 * Wp + xp) * 32 + ppart, Wp * 32, invp);
+          }
+        }
       }
     } else {
       const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -397,12 +430,12 @@ static bool s16_eligible(const ConvArgs& a) {
   if (a.taps != 9 || a.prec != 1 || a.in0.fmt != 1 || a.in1.c != 0 || a.cin != 16 * D_NCH || a.in0.c != a.cin) return false;
   if (a.act > ACT_RELU || a.W < 32 || (a.cout & 15)) return false;
   if (a.store == ST_S16P) { if (a.npad != 32) return false; }
-  else if (a.store == ST_NHWC || a.store == ST_NHWC_POOL || a.store == ST_NHWC_BOTH) { if (a.npad != 64) return false; }
+  else if (a.store == ST_NHWC || a.store == ST_NHWC_POOL || a.store == ST_NHWC_BOTH || a.store == ST_S16P_BOTH) { if (a.npad != 64) return false; }
   else return false;
-  if ((a.store == ST_NHWC_POOL || a.store == ST_NHWC_BOTH) && ((a.H | a.W) & 1)) return false;
+  if ((a.store == ST_NHWC_POOL || a.store == ST_NHWC_BOTH || a.store == ST_S16P_BOTH) && ((a.H | a.W) & 1)) return false;
   if (a.in0.bs != (long)a.H * a.W * a.cin) return false;                      // dense S16P frames
   if ((long)a.H * a.W * a.cin * 4 >= 0x7ffffff0L) return false;
-  const long os = a.store == ST_S16P ? a.cout : (a.os0 > a.os1 ? a.os0 : a.os1);
+  const long os = (a.store == ST_S16P || a.store == ST_S16P_BOTH) ? a.cout : (a.os0 > a.os1 ? a.os0 : a.os1);
   if ((long)a.H * a.W * os * 4 >= 0x7ffffff0L) return false;
   return true;
 }
@@ -461,13 +494,14 @@ int launch_conv3x3_f16x3_s16(const ConvArgs& a0, hipStream_t s) {
     case ST_S16P: return s16_launch_one<ST_S16P, 2>(a, grid, nitems, s);
     case ST_NHWC: return s16_launch_one<ST_NHWC, 4>(a, grid, nitems, s);
     case ST_NHWC_BOTH: return s16_launch_one<ST_NHWC_BOTH, 4>(a, grid, nitems, s);
+    case ST_S16P_BOTH: return s16_launch_one<ST_S16P_BOTH, 4>(a, grid, nitems, s);
     default: return s16_launch_one<ST_NHWC_POOL, 4>(a, grid, nitems, s);
   }
 }
 
 // ---- S16P -> planar fp32 (kp2d_set_tap on a layer whose output is kept split): x = float(hi) + float(lo), which is the
 // fp32 activation to within its last bit or two (lo is x - hi rounded to 11 bits) ----
-__global__ __launch_bounds__(256) void s16p_to_nchw_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int C, int H, int W, long total) {
+__global__ __launch_bounds__(256) void s16p_to_nchw_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int C, int H, int W, int Ct, int c0, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int x = (int)(e % W);
@@ -476,14 +510,15 @@ __global__ __launch_bounds__(256) void s16p_to_nchw_kernel(const _Float16* __res
   r /= H;
   const int c = (int)(r % C);
   const long b = r / C;
-  const _Float16* p = in + (((b * (C / 16) + c / 16) * H + y) * 2 * (long)W + x) * 16 + (c & 15);
+  const int cc = c + c0;
+  const _Float16* p = in + (((b * (Ct / 16) + cc / 16) * H + y) * 2 * (long)W + x) * 16 + (cc & 15);
   out[e] = (float)p[0] + (float)p[(long)W * 16];
 }
-int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s) {
+int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Ct, int c0, hipStream_t s) {
   const long total = (long)B * C * H * W;
   if (total <= 0) return 0;
   hipLaunchKernelGGL(s16p_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                     reinterpret_cast<const _Float16*>(in), out, C, H, W, total);
+                     reinterpret_cast<const _Float16*>(in), out, C, H, W, Ct, c0, total);
   return (int)hipGetLastError();
 }
 

@@ -49,6 +49,10 @@ constexpr int M_PT = 256;                              // staging threads
 constexpr int M_IT = (M_G + M_PT - 1) / M_PT;          // granules per staging thread (10)
 __host__ __device__ constexpr int m_pieces(int n) { return m_wslab(n) / 1024; }       // 1-KiB LDS-DMA pieces of a weight slab (36 / 18)
 constexpr int M_THREADS = 768;
+// IN16 (S16P inputs): a halo image as 1-KiB LDS-DMA pieces, as conv3x3_s16.hip
+constexpr int M_NPIECE = (M_IMG + 1023) / 1024;        // 41: the last one is half a piece
+constexpr int M_IPW = (M_NPIECE + 3) / 4;              // image pieces per staging wave and step (11; 44 slots: three duplicates)
+static_assert(M_NPIECE == 41 && M_IMG - 1024 * (M_NPIECE - 1) == 512, "the last image piece is its first 32 lanes");
 static_assert(m_wslab(32) % 1024 == 0 && m_wslab(64) % 1024 == 0, "weight slabs are whole 1-KiB pieces");
 static_assert(m_lds(64) <= 160 * 1024, "LDS budget");
 
@@ -61,10 +65,19 @@ struct WsmItem { int b, y0, x0, g; };
 
 // STORE: the layer's store mode (kp2d_kernels.h::Store) as a template parameter — the pooled path's registers and DPP code
 // exist only in the two instantiations that pool
-template <int STORE, int NN>
+// IN16: the layer's input(s) are S16P tensors (kp2d_kernels.h) — the staging waves copy the halo image HBM -> LDS by LDS-DMA
+// like the weights, one step ahead (both stages hold image + weights: there is no third image stage to run further ahead, and
+// no register set either), and issue nothing else.
+// S16P outputs (ST_S16P, ST_S16P_SHUFFLE, the upper groups of ST_MIX16): the weight rows of an item's N-tile PAIRS are
+// interleaved on their way into LDS (row 32 p + 16 q + 4 g + i <- channel 32 p + 8 g + 4 q + i), so lane group g of the
+// accumulator tiles (2 p, 2 p + 1) holds channels 32 p + 8 g .. + 7 of its pixel = 16 bytes of a plane; the epilogue
+// splits in registers and stores [8 hi halves] / [8 lo halves] — the same bytes and store count as the fp32 NHWC form.
+template <int STORE, int NN, bool IN16>
 __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const ConvArgs a, const int nitems, const int ntiles) {
   constexpr int M_N = 16 * NN, M_WL = m_wl(M_N), M_WSLAB = m_wslab(M_N), M_STAGE = m_stage(M_N), M_SS = m_ss(M_N);
   constexpr int M_PIECES = m_pieces(M_N), M_PW = (M_PIECES + 3) / 4;      // pieces per staging wave: 9, or 5 / 4
+  constexpr bool S16OUT = STORE == ST_S16P || STORE == ST_S16P_SHUFFLE || STORE == ST_MIX16;
+  static_assert(!(S16OUT || IN16) || NN == 4, "S16P tensors: 64-channel items");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
@@ -147,6 +160,106 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     // of the halo granules) is computed once per item, and a load is four VALU instructions.
     if (KP2D_DBG_ON(256)) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - 512, pw = wave - 8;
+    // weight slab of a step -> stage: piece p = pw + 4 j covers LDS bytes [1024 p, 1024 p + 1024) of [wh plane | wl plane],
+    // each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row: lane l reads row 32 p' + l / 2
+    // (p' = piece inside its plane) — for S16P outputs row 32 p' + perm(l / 2), the N-tile pairs interleaved (above) —
+    // half (l & 1) of the plane's 32 bytes: the lane part is one register for all pieces, the piece part is scalar
+    const int w_row = lane >> 1;
+    const int w_lane_f = w_row * 64 + (lane & 1) * 16;
+    const int w_lane_p = (8 * ((w_row >> 2) & 3) + 4 * (w_row >> 4) + (w_row & 3)) * 64 + (lane & 1) * 16;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, groups * nchunk * M_WSLAB, 0x00020000);
+    auto group_of = [&](int i) { const int j = i * G + off; return groups == 1 ? 0 : j % groups; };
+    auto copy_slab = [&](int stage, int g, int ch) {
+      const int sbase = (g * nchunk + ch) * M_WSLAB;
+      const int w_lane = (STORE == ST_MIX16 ? g * M_N >= a.nsplit : S16OUT) ? w_lane_p : w_lane_f;
+#pragma unroll
+      for (int j = 0; j < M_PW; ++j) {
+        // (18 pieces over four waves: waves 2, 3 copy pieces 0, 1 a second time in their fifth slot — the same bytes to
+        // the same place — so that every wave issues the same straight-line sequence)
+        const int pc = M_PIECES % 4 == 0 ? pw + 4 * j : (pw + 4 * j) % M_PIECES;
+        const int plane = pc >= M_WL / 1024 ? 1 : 0, pp = pc - plane * (M_WL / 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + stage * M_STAGE + M_IMG + 1024 * pc),
+                                                 16, KP2D_DBG_ON(16) ? OOB : w_lane, sbase + 2048 * pp + 32 * plane, 0, 0);
+      }
+    };
+    if constexpr (IN16) {
+      // ---- S16P inputs.  Image piece q = LDS bytes [1024 q, 1024 q + 1024) of [hi plane | lo plane]; lane l brings bytes
+      // 16 l .. + 15 of it: halo pixel slot (py, px), plane, 16-byte half — its source address is the lane's own, lanes
+      // on the zero padding (or on pitch columns 34, 35) point out of range and write zeros.  Wave pw owns pieces
+      // pw + 4 j (j < 11): 41 pieces over 44 slots, the last slots of waves 1-3 copy pieces 0-2 a second time; piece 40
+      // is half a piece (its first 32 lanes).  Per step and wave: 9 weight + 11 image copies, nothing else ----
+      int t_yx[M_IPW], t_ph[M_IPW];
+#pragma unroll
+      for (int j = 0; j < M_IPW; ++j) {
+        int q = pw + 4 * j;
+        if (q >= M_NPIECE) q -= M_NPIECE;
+        const int byte = 1024 * q + 16 * lane;
+        const int plane = byte >= M_LO ? 1 : 0, pb = byte - plane * M_LO;
+        const int sidx = pb >> 5, py = sidx / M_PITCH, px = sidx - py * M_PITCH;
+        t_yx[j] = (byte < M_IMG && px < M_COLS) ? (py << 8) | px : -1;
+        t_ph[j] = plane * W * 32 + ((pb >> 4) & 1) * 16;
+      }
+      const int cs_bytes = H * 2 * W * 32;           // chunk stride of an S16P tensor, bytes
+      int rq_i = 0, rq_ch = 0, rq_b = 0, rq_g = group_of(0);
+      int voff[M_IPW];                               // byte offset of each piece's 16 bytes inside (frame, chunk), or OOB
+      auto enter_item = [&](int i) {
+        const WsmItem r = decode(i);
+        rq_b = r.b; rq_g = r.g;
+        const int y0 = r.y0 - 1, x0 = r.x0 - 1;
+#pragma unroll
+        for (int j = 0; j < M_IPW; ++j) {
+          const int gy = y0 + (t_yx[j] >> 8), gx = x0 + (t_yx[j] & 255);
+          const bool ok = t_yx[j] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          voff[j] = ok ? (gy * 2 * W + gx) * 32 + t_ph[j] : OOB;
+        }
+      };
+      enter_item(0);
+      // the step under the cursor -> `stage` (weights, then image), then advance.  Past the last step the cursor stays on
+      // it: the look-ahead beyond the end re-reads the last step's operands into a stage nobody multiplies
+      auto request = [&](int stage) {
+        copy_slab(stage, rq_g, rq_ch);
+        const bool first = rq_ch * 16 < c0;
+        const ConvSrc& src = first ? a.in0 : a.in1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(src.p) + (size_t)rq_b * src.bs, 0, (int)(src.bs * 4), 0x00020000);
+        const int so = ((src.o >> 4) + (first ? rq_ch : rq_ch - (c0 >> 4))) * cs_bytes;
+        char* const dst = sm + stage * M_STAGE;
+#pragma unroll
+        for (int j = 0; j < M_IPW; ++j) {
+          int q = pw + 4 * j;
+          if (q >= M_NPIECE) q -= M_NPIECE;
+          if (j == M_IPW - 1) {
+            // wave 0: piece 40, the image's last 512 bytes (lanes 32-63 would write into the weights); waves 1-3: a duplicate
+            if (pw != 0 || lane < 32)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 1024 * q), 16,
+                                                       KP2D_DBG_ON(32) ? OOB : voff[j], so, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 1024 * q), 16,
+                                                     KP2D_DBG_ON(32) ? OOB : voff[j], so, 0, 0);
+          }
+        }
+        if (rq_ch + 1 < nchunk) ++rq_ch;
+        else if (rq_i + 1 < n_my) { rq_ch = 0; enter_item(++rq_i); }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto wait_landed = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): LDS-DMA counts in vmcnt
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      request(0);                                      // step 0
+      wait_landed();
+      __syncthreads();                                 // barrier 0: stage 0 holds step 0 (and scale | shift are in LDS)
+      for (int s = 0; s < nsteps_p; ++s) {
+        request((s + 1) & 1);                          // step s + 1 -> the stage step s - 1 was multiplied out of
+        wait_landed();
+        // a bare s_barrier: __syncthreads() is fence + barrier, and this role neither reads LDS nor writes it other than by
+        // the copies the counted wait above has seen land (conv3x3_s16.hip)
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
     // granule gi = ptid + 256 it of a halo image = (halo pixel hp = gi / 4 = (py, px), channels 4 (gi % 4) ...)
     int g_yx[M_IT], g_lds[M_IT];
 #pragma unroll
@@ -158,8 +271,6 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
     }
     const int q16 = (ptid & 3) * 16;
     const int ps0 = (int)a.in0.ps * 4, ps1 = (int)a.in1.ps * 4;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, groups * nchunk * M_WSLAB, 0x00020000);
     float4 rin[2][M_IT];
 
     // cursors over the flat step sequence: one for the input requests, one for the weight copies.  Past the last step
@@ -180,7 +291,6 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
         pix[it] = ok ? (tr ? gx * Wg + gy : gy * Wg + gx) : -1;
       }
     };
-    auto group_of = [&](int i) { const int j = i * G + off; return groups == 1 ? 0 : j % groups; };
     enter_item(0);
     dm_g = group_of(0);
     auto request = [&](auto set_c) {                 // loads of the step under the request cursor, then advance it
@@ -215,22 +325,8 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
         *reinterpret_cast<f16x4*>(sm + M_LO + lb) = f16x4{l0[0], l0[1], l1[0], l1[1]};
       }
     };
-    // weight slab of the step under the copy cursor -> stage: piece p = pw + 4 j covers LDS bytes [1024 p, 1024 p + 1024)
-    // of [wh plane | wl plane], each [slot][n][32 B]; a lane's 16 bytes come from the packed [16 hi | 16 lo] row: lane l
-    // reads row 32 p' + l / 2 (p' = piece inside its plane), half (l & 1) of the plane's 32 bytes — the lane part is one
-    // register for all pieces, the piece part is scalar (the instruction's soffset)
-    const int w_lane = (lane >> 1) * 64 + (lane & 1) * 16;
-    auto copy_w = [&](int stage) {
-      const int sbase = (dm_g * nchunk + dm_ch) * M_WSLAB;
-#pragma unroll
-      for (int j = 0; j < M_PW; ++j) {
-        // (18 pieces over four waves: waves 2, 3 copy pieces 0, 1 a second time in their fifth slot — the same bytes to
-        // the same place — so that every wave issues the same straight-line sequence)
-        const int pc = M_PIECES % 4 == 0 ? pw + 4 * j : (pw + 4 * j) % M_PIECES;
-        const int plane = pc >= M_WL / 1024 ? 1 : 0, pp = pc - plane * (M_WL / 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sm + stage * M_STAGE + M_IMG + 1024 * pc),
-                                                 16, KP2D_DBG_ON(16) ? OOB : w_lane, sbase + 2048 * pp + 32 * plane, 0, 0);
-      }
+    auto copy_w = [&](int stage) {                   // the step under the copy cursor, then advance it
+      copy_slab(stage, dm_g, dm_ch);
       if (dm_ch + 1 < nchunk) ++dm_ch;
       else if (dm_i + 1 < n_my) { dm_ch = 0; dm_g = group_of(++dm_i); }
       __builtin_amdgcn_sched_barrier(0);             // the counted wait (WAIT_W) needs the copies OLDER than the next request
@@ -333,6 +429,67 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       }
     }
   };
+#ifdef KP2D_ABLATE
+  // (timing ablation, KP2D_DBG bit 4: the same MFMA sequence with the operands of the first slot pair read ONCE per step —
+  // what a step costs when no product ever waits for an LDS read.  Bit 128: the reads of every slot, one v_pk_add per
+  // operand instead of the MFMAs — what the LDS side alone costs.)
+  auto multiply_once = [&](int sb) {
+    f16x8 bh[NN], bl[NN], zh[MT], zl[MT];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      bh[n] = *reinterpret_cast<const f16x8*>(sm + sb + b_p + n * 512);
+      bl[n] = *reinterpret_cast<const f16x8*>(sm + sb + b_p + n * 512 + M_WL);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mo = (2 * (m / CB) * M_PITCH + 8 * (m % CB)) * M_PXB;
+      zh[m] = *reinterpret_cast<const f16x8*>(sm + sb + a_dx + mo);
+      zl[m] = *reinterpret_cast<const f16x8*>(sm + sb + a_dx + mo + M_LO);
+    }
+#pragma unroll
+    for (int slot = 0; slot < 9; slot += 2) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+          if (slot == 8) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh[m], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh[m], acc[m][n], 0, 0, 0);
+          } else {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl[m], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh[m], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh[m], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+  };
+  auto multiply_reads = [&](int sb) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 sum = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int slot = 0; slot < 9; slot += 2) {
+      const int tp = m_slot_tap(slot);
+      const bool single = slot == 8;
+      const bool dy = slot == 4;
+      const int ab = sb + (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(tp);
+      const int bb = sb + (single ? b_s : b_p) + slot * M_N * 32;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        sum += *reinterpret_cast<const h8*>(sm + bb + n * 512);
+        sum += *reinterpret_cast<const h8*>(sm + bb + n * 512 + M_WL);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mo = (2 * (m / CB) * M_PITCH + 8 * (m % CB)) * M_PXB;
+        sum += *reinterpret_cast<const h8*>(sm + ab + mo);
+        if (!single) sum += *reinterpret_cast<const h8*>(sm + ab + mo + M_LO);
+      }
+    }
+    acc[0][0][0] += (float)sum[0] + (float)sum[1] + (float)sum[2] + (float)sum[3] + (float)sum[4] + (float)sum[5] + (float)sum[6] + (float)sum[7];
+  };
+#endif
   // ---- epilogue.  Accumulator tile (m, n): lane (lp, lg) holds pixel lp of M-tile m, channels 16 n + 4 lg .. + 3 of the
   // item's group.  A lane's byte offset per M-tile (pixel part, padding lanes ORed out of range) is computed once per
   // item; the channel / sub-pixel part of an N-tile is wave-uniform: one scalar added per store.
@@ -346,10 +503,77 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   // (2.36 ms for the layers that take 1.96 ms this way), with branch-skipped pieces 2.12 ms.) ----
   constexpr bool full = store != ST_NHWC_POOL;
   constexpr bool pooled = store == ST_NHWC_POOL || store == ST_NHWC_BOTH;
-  constexpr int up = store == ST_SHUFFLE ? 2 : 1;
+  constexpr int up = (store == ST_SHUFFLE || store == ST_S16P_SHUFFLE) ? 2 : 1;
   const int HH = a.H * up, WW = a.W * up, Hp = a.H >> 1, Wp = a.W >> 1;      // the outputs, as they lie in memory
   const int cq = a.cout >> 2;
+  // S16P output of an item: per N-tile pair p the lane group lg holds channels cn + 8 lg .. + 7 (cn = 64 g + 32 p) of its
+  // pixel — chunk (cn + 8 lg) / 16, halves 8 (lg & 1) .. + 7 — as two accumulator tiles; split2 as a consumer's staging
+  // would have done it, two 16-byte stores (hi plane, lo plane) per M-tile.  ST_S16P_SHUFFLE: a pair is one sub-pixel
+  // (cout / 4 is a multiple of 32).  ST_MIX16: the S16P tensor is out1 and starts at channel nsplit.
+  auto finish16 = [&](const WsmItem& it) {
+    // (lane-derived values of this epilogue are recomputed per item from an opaque copy of the lane index: hoisted out of the
+    // step loop they cost the registers the multiply phase needs — ST_MIX16, with both epilogues, spilled eight of them)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lg = lane_o >> 4, lp = lane_o & 15;
+    float* const op = store == ST_MIX16 ? a.out1 : a.out0;
+    const int Ct = store == ST_MIX16 ? a.os1 : a.os0;                      // channels of the S16P tensor
+    const int cbase = store == ST_MIX16 ? a.nsplit - a.oo1 : -a.oo0;       // layer channel of the tensor's channel 0
+    const int obs = HH * WW * Ct;                                         // frame stride, floats (= bytes / 4)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(op + (size_t)it.b * obs, 0, obs * 4, 0x00020000);
+    const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
+    int vo[MT], vi[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int y = it.y0 + wr * 4 + 2 * (m / CB) + prow, x = it.x0 + 16 * ph + 8 * (m % CB) + pcol;
+      vo[m] = (up * y * 2 * WW + up * x) * 32;
+      vi[m] = (y < H && x < W) ? 0 : OOB;
+    }
+#pragma unroll
+    for (int pr = 0; pr < NN / 2; ++pr) {
+      const int cn = it.g * M_N + pr * 32;                                // first channel of the pair (wave-uniform)
+      if (cn >= a.cout) continue;
+      const int cl = cn + 8 * lg;                                         // this lane's first channel
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sm + M_SS + cl * 4);
+      const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sm + M_SS + (cl + 4) * 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(sm + M_SS + (M_MAXN + cl) * 4);
+      const f32x4 sh1 = *reinterpret_cast<const f32x4*>(sm + M_SS + (M_MAXN + cl + 4) * 4);
+      const int cinv = cl < a.cout ? 0 : OOB;                             // chunks past cout (a multiple of 16)
+      int cpart;
+      if (store == ST_S16P_SHUFFLE) {
+        const int sub = cn / cq, oc = cl - sub * cq - cbase;
+        cpart = (oc >> 4) * (HH * 2 * WW * 32) + ((sub >> 1) * 2 * WW + (sub & 1)) * 32 + (lg & 1) * 16;
+      } else {
+        cpart = ((cl - cbase) >> 4) * (HH * 2 * WW * 32) + (lg & 1) * 16;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto affine = [&](const f32x4 v, const f32x4 sc, const f32x4 sh) -> f32x4 {
+          const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+          const f32x2 t01 = __builtin_elementwise_fma(a01, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+          const f32x2 t23 = __builtin_elementwise_fma(a23, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+          const f32x2 u01 = t01 * slope, u23 = t23 * slope;
+          return f32x4{fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1]), fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
+        };
+        const f32x4 v0 = affine(acc[m][2 * pr], sc0, sh0), v1 = affine(acc[m][2 * pr + 1], sc1, sh1);
+        f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+        split2(v0[0], v0[1], h0, l0);
+        split2(v0[2], v0[3], h1, l1);
+        split2(v1[0], v1[1], h2, l2);
+        split2(v1[2], v1[3], h3, l3);
+        const i32x4 hi = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+        const i32x4 lo = {__builtin_bit_cast(int, l0), __builtin_bit_cast(int, l1), __builtin_bit_cast(int, l2), __builtin_bit_cast(int, l3)};
+        const int o = vo[m] + cpart, inv = vi[m] | cinv;
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rs, KP2D_DBG_ON(64) ? OOB : (o | inv), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rs, KP2D_DBG_ON(64) ? OOB : ((o + WW * 32) | inv), 0, 0);
+      }
+    }
+  };
   auto finish = [&](const WsmItem& it) {
+    if constexpr (S16OUT) {
+      if (store != ST_MIX16 || it.g * M_N >= a.nsplit) { finish16(it); return; }
+    }
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         a.out0 + (size_t)it.b * HH * WW * a.os0, 0, full ? HH * WW * a.os0 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -435,6 +659,11 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   for (int s = 0; s < nsteps_p; ++s) {
     if (s < nsteps) {
       if (due) { finish(prev); clear(); due = false; }
+#ifdef KP2D_ABLATE
+      if (busy && KP2D_DBG_ON(4)) multiply_once((s & 1) * M_STAGE);
+      else if (busy && KP2D_DBG_ON(128)) multiply_reads((s & 1) * M_STAGE);
+      else
+#endif
       if (busy && !KP2D_DBG_ON(8)) multiply((s & 1) * M_STAGE);
       if (++ch == nchunk) {
         if (busy && !KP2D_DBG_ON(1)) {
@@ -456,17 +685,33 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
 // true when the layer can run as the kernel above (launch_conv3x3_f16x3 falls back to the general kernel otherwise)
 static bool wsm_eligible(const ConvArgs& a, int N) {
   if (a.taps != 9 || a.prec != 1 || a.ng32 || a.npad % N != 0 || a.npad > M_MAXN) return false;
-  if (a.store != ST_NHWC && a.store != ST_SHUFFLE && a.store != ST_NHWC_BOTH && a.store != ST_NHWC_POOL) return false;
+  const bool s16out = a.store == ST_S16P || a.store == ST_S16P_SHUFFLE || a.store == ST_MIX16;
+  if (a.store != ST_NHWC && a.store != ST_SHUFFLE && a.store != ST_NHWC_BOTH && a.store != ST_NHWC_POOL && !s16out) return false;
   if (a.act > ACT_RELU) return false;
   if (((a.in0.c | a.cin) & 15) != 0 || a.cin < 32) return false;      // whole 16-channel chunks, never straddling the sources
   if (a.cout & 3) return false;
   if (a.store == ST_SHUFFLE && ((a.cout >> 2) & 15)) return false;      // a 16-channel N-tile is one sub-pixel
   if (a.W < 32) return false;
-  if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return false;
   const long ps = a.in0.ps > a.in1.ps ? a.in0.ps : a.in1.ps;
   if ((long)a.H * a.W * ps * 4 >= 0x7ffffff0L) return false;
-  const long up = a.store == ST_SHUFFLE ? 4 : 1;
+  if (a.in0.fmt == 1) {
+    // S16P sources: whole chunks of dense tensors (a view is a run of chunks: ps = the tensor's channels)
+    if (N != 64 || (a.in1.c > 0 && a.in1.fmt != 1) || ((a.in0.o | a.in1.o) & 15)) return false;
+    if (a.in0.bs != (long)a.H * a.W * a.in0.ps || (a.in1.c > 0 && a.in1.bs != (long)a.H * a.W * a.in1.ps)) return false;
+  } else {
+    if (a.in1.c > 0 && a.in1.fmt == 1) return false;
+    if (a.in0.rs != (long)a.W * a.in0.ps || (a.in1.c > 0 && a.in1.rs != (long)a.W * a.in1.ps)) return false;
+  }
+  if (s16out) {
+    // whole chunks out, 64-channel items, a pair of N-tiles = 32 channels of one sub-pixel
+    if (N != 64 || (a.cout & 15)) return false;
+    if (a.store == ST_S16P_SHUFFLE && (((a.cout >> 2) & 31) || (a.os0 & 15) || (a.oo0 & 15))) return false;
+    if (a.store == ST_S16P && ((a.os0 & 15) || (a.oo0 & 15))) return false;
+    if (a.store == ST_MIX16 && ((a.nsplit & 63) || a.nsplit <= 0 || a.nsplit >= a.cout || (a.os1 & 15) || (a.oo1 & 15) || (a.os0 & 3))) return false;
+  }
+  const long up = (a.store == ST_SHUFFLE || a.store == ST_S16P_SHUFFLE) ? 4 : 1;
   if ((long)a.H * a.W * up * a.os0 * 4 >= 0x7ffffff0L) return false;
+  if (a.store == ST_MIX16 && (long)a.H * a.W * a.os1 * 4 >= 0x7ffffff0L) return false;
   return true;
 }
 
@@ -489,20 +734,35 @@ static int wsm_walk_cost(int Ht, int Wt) {
   return cost;
 }
 
-template <int STORE, int NN>
+template <int STORE, int NN, bool IN16 = false>
 static int wsm_launch_one(const ConvArgs& a, int grid, long nitems, long ntiles, hipStream_t s) {
   static PerDeviceOnce lds_once;      // per instantiation and device
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<STORE, NN>))) return e;
-  hipLaunchKernelGGL((conv3x3_f16x3_wsm_kernel<STORE, NN>), dim3(grid), dim3(M_THREADS), m_lds(16 * NN), s, a, (int)nitems, (int)ntiles);
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_wsm_kernel<STORE, NN, IN16>))) return e;
+  hipLaunchKernelGGL((conv3x3_f16x3_wsm_kernel<STORE, NN, IN16>), dim3(grid), dim3(M_THREADS), m_lds(16 * NN), s, a, (int)nitems, (int)ntiles);
   return (int)hipGetLastError();
 }
 template <int NN>
 static int wsm_launch(const ConvArgs& a, int grid, long nitems, long ntiles, hipStream_t s) {
+  if constexpr (NN == 4) {
+    if (a.in0.fmt == 1) {             // S16P inputs (the plan's big-grid layout, kp2d_api.cpp)
+      switch (a.store) {
+        case ST_NHWC: return wsm_launch_one<ST_NHWC, 4, true>(a, grid, nitems, ntiles, s);
+        case ST_NHWC_POOL: return wsm_launch_one<ST_NHWC_POOL, 4, true>(a, grid, nitems, ntiles, s);
+        case ST_S16P: return wsm_launch_one<ST_S16P, 4, true>(a, grid, nitems, ntiles, s);
+        case ST_S16P_SHUFFLE: return wsm_launch_one<ST_S16P_SHUFFLE, 4, true>(a, grid, nitems, ntiles, s);
+        case ST_MIX16: return wsm_launch_one<ST_MIX16, 4, true>(a, grid, nitems, ntiles, s);
+        default: return -1006;
+      }
+    }
+    if (a.store == ST_S16P_SHUFFLE) return wsm_launch_one<ST_S16P_SHUFFLE, 4>(a, grid, nitems, ntiles, s);
+    if (a.store == ST_S16P || a.store == ST_MIX16) return -1006;
+  }
   switch (a.store) {
     case ST_NHWC: return wsm_launch_one<ST_NHWC, NN>(a, grid, nitems, ntiles, s);
     case ST_SHUFFLE: return wsm_launch_one<ST_SHUFFLE, NN>(a, grid, nitems, ntiles, s);
     case ST_NHWC_BOTH: return wsm_launch_one<ST_NHWC_BOTH, NN>(a, grid, nitems, ntiles, s);
-    default: return wsm_launch_one<ST_NHWC_POOL, NN>(a, grid, nitems, ntiles, s);
+    case ST_NHWC_POOL: return wsm_launch_one<ST_NHWC_POOL, NN>(a, grid, nitems, ntiles, s);
+    default: return -1006;
   }
 }
 
@@ -522,9 +782,10 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   // 32-channel items are correct (bit-identical, tested through kp2d_set_option) but not faster: conv2a / 2b / 3a 0.088-0.094 ms
   // against 0.087-0.089 ms on the wide LDS-DMA tiles, -0.8 % end to end (profiles/r4_ab_wsm32.txt) — automatic use is off
   static const bool n32_on = getenv("KP2D_WSM32") && getenv("KP2D_WSM32")[0] == '1';
-  if (a0.wsm_min < 0 || (a0.wsm_min == 0 && min_env == 0)) return -1000;
-  if (n_item != 64 && n_item != 32) return -1000;
-  if (!wsm_eligible(a0, n_item)) return -1000;
+  const bool forced = a0.wsm_force != 0;      // S16P in or out: the plan already asked conv3x3_wsm_would_run; no other kernel takes the layout
+  if (!forced && (a0.wsm_min < 0 || (a0.wsm_min == 0 && min_env == 0))) return -1000;
+  if (n_item != 64 && n_item != 32) return forced ? -1006 : -1000;
+  if (!wsm_eligible(a0, n_item)) return forced ? -1006 : -1000;
   ConvArgs a = a0;
   // Transposed walk (tile rows = map columns; needs the layer's transposed-tap pack).  OFF unless asked for: it sums the nine
   // taps in another order than every other form, and the engine's results are bit-identical whatever the batch size, lane
@@ -533,7 +794,8 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   static const int tr_env = getenv("KP2D_WSM_TR") ? atoi(getenv("KP2D_WSM_TR")) : 0;
   const int tr_mode = a0.wsm_tr != 0 ? a0.wsm_tr : tr_env;
   a.wsm_tr = 0;
-  if (n_item == 64 && a.w_tr && tr_mode > 0 && a.H >= 16 && (tr_mode == 1 || wsm_walk_cost(a.W, a.H) < wsm_walk_cost(a.H, a.W))) {
+  const bool s16_any = a.in0.fmt == 1 || a.store == ST_S16P || a.store == ST_S16P_SHUFFLE || a.store == ST_MIX16;      // S16P rows are map rows
+  if (n_item == 64 && a.w_tr && tr_mode > 0 && !s16_any && a.H >= 16 && (tr_mode == 1 || wsm_walk_cost(a.W, a.H) < wsm_walk_cost(a.H, a.W))) {
     a.wsm_tr = 1;
     a.w = a.w_tr;
   }
@@ -554,16 +816,36 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   // 64-channel items, at least four chunks (conv3b, two chunks and two stores per item, is slower in this form: 0.165
   // against 0.157 ms)
   const long min_items = a.wsm_min > 0 ? a.wsm_min : (min_env > 0 ? min_env : 2 * cap + 1);
-  if (cap < 8 || nitems < min_items || nitems >= (1L << 30)) return -1000;
-  if (automatic && n_item == 64 && a.cin < 64) return -1000;
-  if (automatic && n_item == 32 && !n32_on) return -1000;
+  if (cap < 8 || nitems >= (1L << 30)) return forced ? -1006 : -1000;
+  if (!forced) {
+    if (nitems < min_items) return -1000;
+    if (automatic && n_item == 64 && a.cin < 64) return -1000;
+    if (automatic && n_item == 32 && !n32_on) return -1000;
+  }
   const long rounds = (nitems + cap - 1) / cap;
   int grid = (int)(((nitems + rounds - 1) / rounds + 7) & ~7L);
   if (grid > cap) grid = cap;
   if (grid > nitems) grid = (int)(nitems & ~7L);
-  if (grid < 8) return -1000;
-  conv3x3_note_variant(n_item == 32 ? "<wsm32>" : (a.wsm_tr ? "<wsm>t" : "<wsm>"));      // (what the engine's profile records)
+  if (grid < 8) return forced ? -1006 : -1000;
+  conv3x3_note_variant(n_item == 32 ? "<wsm32>" : (a.wsm_tr ? "<wsm>t" : (a.in0.fmt == 1 ? (s16_any && a.store != ST_NHWC && a.store != ST_NHWC_POOL ? "<wsm>s16io" : "<wsm>s16in") : (s16_any ? "<wsm>s16out" : "<wsm>"))));      // (what the engine's profile records)
   return n_item == 64 ? wsm_launch<4>(a, grid, nitems, ntiles, s) : wsm_launch<2>(a, grid, nitems, ntiles, s);
+}
+
+// the automatic policy above for a 64-channel-group layer (the plan fixes the S16P layout of the big-grid forward on the
+// answer for its smallest such layer, backbone.conv4a)
+bool conv3x3_wsm_would_run(int B, int H, int W, int groups, int lanes, int wsm_min, int grid_opt) {
+  static const long min_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : -1;
+  static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;
+  if (wsm_min < 0 || (wsm_min == 0 && min_env == 0) || W < 32) return false;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  else (void)hipGetLastError();
+  int cap = grid_opt > 0 ? grid_opt : (grid_env > 0 ? grid_env : cus / (lanes > 1 ? lanes : 1));
+  if (cap > cus) cap = cus;
+  cap &= ~7;
+  const long nitems = (long)((W + M_TW - 1) / M_TW) * ((H + M_TH - 1) / M_TH) * B * groups;
+  const long min_items = wsm_min > 0 ? wsm_min : (min_env > 0 ? min_env : 2 * cap + 1);
+  return cap >= 8 && nitems >= min_items && nitems < (1L << 30);
 }
 
 }  // namespace kp2d

@@ -124,7 +124,7 @@ struct Act {
   size_t off = 0, bytes = 0;
   int C = 0, H = 0, W = 0;
   int PS = 0, CO = 0;  // channel-slice view of a wider tensor: pixel stride (0 = C) and first channel; bytes = 0 (not owned)
-  int fmt = 0;         // 1: an S16P tensor (kp2d_kernels.h: the fp16 halves of the split, planar rows; same bytes), never a view
+  int fmt = 0;         // 1: an S16P tensor (kp2d_kernels.h: the fp16 halves of the split, planar rows; same bytes); a view is a run of whole chunks
 };
 
 }  // namespace
@@ -155,6 +155,7 @@ struct kp2d_model {
   int stem_fusion = getenv("KP2D_STEM") ? std::max(0, std::min(2, atoi(getenv("KP2D_STEM")))) : 1;
   size_t conv1a_ws = 0;       // blob offset of 2^e, the scale conv1a's weights are split at (pack(); in the blob, so that it travels with an RCCL weight broadcast)
   bool multi_launch = true;   // kp2d_set_option("multi_launch"): independent layers of a level as one launch on small grids
+  bool s16_all = true;        // kp2d_set_option("s16_all"): big grids keep every tensor the warp-specialised 3x3 layers read as S16P (build())
   int s16_min = 0;        // kp2d_set_option("s16_min_items"): conv3x3_s16.hip — 0 = automatic (three rounds of tiles per workgroup), N = from N tiles, < 0 = never
   int precision = KP2D_PREC_F16X3;
   std::map<uint64_t, size_t> plan_cache;
@@ -641,7 +642,7 @@ struct Plan {
     if (dry || rc != KP2D_OK || !m->tap_dst || name != m->tap_name) return;
     const size_t per = (size_t)a.C * a.H * a.W;
     if (((size_t)b0 + B) * per > m->tap_cap) { rc = fail(KP2D_ERR_ARG, "tap '%s': buffer holds %zu floats, needs %zu", name.c_str(), m->tap_cap, ((size_t)b0 + B) * per); return; }
-    if (a.fmt == 1) check(launch_s16p_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H, a.W, stream), name.c_str());
+    if (a.fmt == 1) check(launch_s16p_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H, a.W, a.PS ? a.PS : a.C, a.CO, stream), name.c_str());
     else check(launch_nhwc_to_nchw(ptr(a), m->tap_dst + (size_t)b0 * per, B, a.C, a.H * a.W, a.PS ? a.PS : a.C, a.CO, stream), name.c_str());
   }
 
@@ -707,6 +708,10 @@ struct Plan {
     a.ws_min = m->ws_min;
     a.wsm_lanes = nlanes;
     a.s16_min = m->s16_min;
+    // S16P tensors beyond the 32-channel stage are read and written by conv3x3_wsm.hip only: build() fixed the layout
+    // after asking conv3x3_wsm_would_run, the launcher then skips its item-count policy
+    a.wsm_force = ((s0.fmt == 1 && !(c.cin == 32 && s1.c == 0)) || store == ST_S16P_SHUFFLE || store == ST_MIX16 ||
+                   (store == ST_S16P && c.npad >= 64)) ? 1 : 0;
     if (stem_x && name == "backbone.conv1b") {
       a.stem_x = stem_x; a.stem_w = m->blob + m->conv1a_w; a.stem_scale = m->blob + m->conv1a_sc; a.stem_shift = m->blob + m->conv1a_sh;
       a.stem_wscale = m->blob + m->conv1a_ws; a.stem_act = m->cfg.leaky_relu ? ACT_LEAKY : ACT_RELU;
@@ -718,7 +723,7 @@ struct Plan {
     // few workgroups is a long serial chain; 32-channel groups double the workgroups and halve their length.
     // (a forced warp-specialised form — kp2d_set_option("wsm_min_items"), the parity tests — keeps its 64-channel groups)
     const bool wsm_forced = m->wsm_min > 0 && (long)((Wc + 31) / 32) * ((Hc + 15) / 16) * B * (c.npad / 64) >= m->wsm_min;
-    if (split && c.npad >= 64 && m->small_grid_ng32 && !wsm_forced && s0.fmt == 0 &&      // (an S16P input: conv3x3_s16.hip, 64-channel groups)
+    if (split && c.npad >= 64 && m->small_grid_ng32 && !wsm_forced && s0.fmt == 0 && !a.wsm_force &&      // (S16P tensors: 64-channel groups)
         (long)a.tiles_x * a.tiles_y * B * (c.npad / 64) < 256) {
       a.w = m->blob + c.w16n_off;
       a.ng32 = 1;
@@ -763,6 +768,9 @@ struct Plan {
     }
     const char* fam = split ? (c.taps == 9 ? "conv3x3_f16x3" : "conv1x1_f16x3")
                             : (c.taps == 9 ? (c.kc == 16 ? "conv3x3_f32<16>" : "conv3x3_f32<8>") : "conv1x1_f32");
+    if (a.stem_x)      // conv1a computed inside this launch: its products count, its input is the 3-channel frame
+      prof_begin(name, fam, 2.0 * 9 * (3.0 * 16 + c.cin * c.cout) * px, 4.0 * px * (3 + c.cout / 4.0) + 4.0 * 9 * c.cin * c.cout);
+    else
     prof_begin(name, fam, 2.0 * c.taps * c.cin * c.cout * px, 4.0 * px * (c.cin + c.cout) + 4.0 * c.taps * c.cin * c.cout);
     check(launch_conv3x3(a, split ? 16 : c.kc, stream), name.c_str());
     if (m->profiling && !dry) m->prof[m->prof_used].kernel += conv3x3_last_variant();      // which tile form ran
@@ -927,6 +935,16 @@ struct Plan {
       out = alloc(c.cout, Hc / 2, Wc / 2);
       out.fmt = 1;
       conv(name, in0, in0.C, 0, in1, act, store, nullptr, 0, 0, dry ? nullptr : ptr(out), c.cout, 0, 0, Hc, Wc);
+    } else if (store == ST_S16P_BOTH) {
+      out = alloc(c.cout, Hc, Wc);
+      *pooled = alloc(c.cout, Hc / 2, Wc / 2);
+      out.fmt = pooled->fmt = 1;
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout, 0, dry ? nullptr : ptr(*pooled),
+           c.cout, 0, 0, Hc, Wc);
+    } else if (store == ST_S16P_SHUFFLE) {
+      out = alloc(c.cout / 4, Hc * 2, Wc * 2);
+      out.fmt = 1;
+      conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
     } else {  // ST_SHUFFLE
       out = alloc(c.cout / 4, Hc * 2, Wc * 2);
       conv(name, in0, in0.C, 0, in1, act, store, dry ? nullptr : ptr(out), c.cout / 4, 0, nullptr, 0, 0, 0, Hc, Wc);
@@ -997,15 +1015,6 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   P.release(t2a);
   Act t3a = P.cbr("backbone.conv3a", t2b, nullptr, s16 ? ST_S16P : ST_NHWC);
   P.release(t2b);
-  Act xp{};
-  Act skip = P.cbr("backbone.conv3b", t3a, nullptr, ST_NHWC_BOTH, &xp);   // downsample >= 1 always
-  P.release(t3a);
-  Act t4a = P.cbr("backbone.conv4a", xp, nullptr, ST_NHWC);
-  P.release(xp);
-  Act xb = P.cbr("backbone.conv4b", t4a, nullptr, ST_NHWC);
-  P.release(t4a);
-  const int Hc = xb.H, Wc = xb.W, H2 = skip.H, W2 = skip.W;
-
   const bool only_enc = (flags & KP2D_FWD_ONLY_ENCODER) != 0;   // only_encoder(): skip every head but the VPR encoder
   // First CBR of every head in one launch ("heads.first", see describe()); first(name) hands out its channel slices.
   static const bool merge_env = !(getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '0');
@@ -1015,17 +1024,58 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // reads in the five consumers: +0.1 ... +0.6 % at 64 frames, +1.4 % at 32, +0.9 % at 16, +0.6 % at 480 x 640, +0.9 % N
   // (profiles/r4_ab_merged_heads.txt); V3 (three parts), fp32 arithmetic and 30 x 40 head maps measured -0.2 ... -0.8 %
   // and keep their own launches.  KP2D_MERGE_HEADS: 0 never, 2 always.
+  const int Hc = H >> g.downsample, Wc = W >> g.downsample;      // the cell grid (backbone output)
   const bool small_grid = (long)((Hc + 15) / 16) * ((Wc + 15) / 16) * P.B < 256;
   static const bool merge_always = getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '2';
   const bool big_wsm = m->precision == KP2D_PREC_F16X3 && !v3 && m->wsm_min >= 0 && (long)Hc * Wc >= 60 * 80;
   const bool merged = merge_env && (small_grid || merge_always || big_wsm) && !only_enc && m->conv_index.count("heads.first");
-  Act mx{};
-  if (merged) mx = P.cbr("heads.first", xb, nullptr, ST_NHWC);
+  // Big grids of the plain V2 S configuration: S16P is the layout of EVERY tensor a split-fp16 3x3 layer of the warp-specialised
+  // form reads — conv3b's two outputs, conv4a / 4b, the merged first layer's desc / seg / vlad slices, both pixel-shuffled
+  // tensors, convs.5, convlad2 — so those layers' staging waves only issue LDS-DMA copies (conv3x3_wsm.hip IN16).  fp32 NHWC
+  // stays where another kernel reads: the score / location slices (exact dot products, head3x3.hip), convs.1's pooled output
+  // and convs.2 / .3 (30 x 40 maps: general kernels), confAa's and convs.7's outputs (confBb / convs.8, planar outputs),
+  // convlad3's (NetVLAD).  Same values bit for bit (a consumer multiplies the halves its own staging would have produced).
+  // Decided once, on the form running for the smallest converted layer (conv4a); a tap keeps its layer readable either way.
+  static const bool s16all_env = !(getenv("KP2D_S16ALL") && getenv("KP2D_S16ALL")[0] == '0');      // (A/B knob)
+  const int Hq = H / 4, Wq = W / 4;
+  const bool s16_all = s16 && s16all_env && m->s16_all && !v3 && !only_enc && !g.use_attention && !g.depth &&
+                       g.upscale_method != KP2D_UP_CONVTRANSPOSE && m->c5 == 64 && m->d1 == 128 && g.encoder_dim == 64 &&
+                       m->wsm_min >= 0 && m->wsm_tr == 0 && merged &&
+                       Wq / 2 >= 32 &&      // (convs.4 writes its pixel-shuffled S16P output from a W / 8 map: the form's least width
+                       (long)((Wq / 2 + 31) / 32) * ((Hq / 2 + 15) / 16) * B * 2 >= 8 &&      //  and its least grid, eight work items)
+                       conv3x3_wsm_would_run(B, Hq, Wq, 1, P.nlanes, m->wsm_min, m->wsm_grid);
+  Act xp{};
+  Act skip = P.cbr("backbone.conv3b", t3a, nullptr, s16_all ? ST_S16P_BOTH : ST_NHWC_BOTH, &xp);   // downsample >= 1 always
+  P.release(t3a);
+  Act t4a = P.cbr("backbone.conv4a", xp, nullptr, s16_all ? ST_S16P : ST_NHWC);
+  P.release(xp);
+  Act xb = P.cbr("backbone.conv4b", t4a, nullptr, s16_all ? ST_S16P : ST_NHWC);
+  P.release(t4a);
+  const int H2 = skip.H, W2 = skip.W;
+  if (xb.H != Hc || xb.W != Wc) { P.rc = fail(KP2D_ERR_ARG, "plan: cell grid %dx%d, expected %dx%d", xb.H, xb.W, Hc, Wc); return; }
+
+  Act mx{}, mxs{};
+  int mx_split = 1 << 30;      // first channel of the merged layer kept in the S16P tensor mxs (s16_all: behind score | loc)
+  if (merged && s16_all) {
+    const ConvPack& cf = m->convs[m->conv_index.at("heads.first")];
+    mx_split = cf.parts[0].second + cf.parts[1].second;
+    mx = P.alloc(mx_split, Hc, Wc);
+    mxs = P.alloc(cf.cout - mx_split, Hc, Wc);
+    mxs.fmt = 1;
+    P.conv("heads.first", xb, xb.C, 0, nullptr, lk, ST_MIX16, P.dry ? nullptr : P.ptr(mx), mx.C, 0, P.dry ? nullptr : P.ptr(mxs), mxs.C, 0,
+           mx_split, Hc, Wc);
+  } else if (merged) {
+    mx = P.cbr("heads.first", xb, nullptr, ST_NHWC);
+  }
   auto first = [&](const std::string& name) -> Act {
     if (merged) {
       int o = 0;
       for (const auto& pt : m->convs[m->conv_index.at("heads.first")].parts) {
-        if (pt.first == name) { Act v = Plan::view(mx, pt.second, o); P.tap(name, v); return v; }
+        if (pt.first == name) {
+          Act v = o < mx_split ? Plan::view(mx, pt.second, o) : Plan::view(mxs, pt.second, o - mx_split);
+          P.tap(name, v);
+          return v;
+        }
         o += pt.second;
       }
     }
@@ -1084,7 +1134,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // (a dry run sizes the workspace for whichever schedule keeps more tensors alive — P.no_levels picks; profiles and taps
   // take the layers one launch at a time)
   const bool levels = merged && small_grid && !v3 && !g.use_attention && !g.depth && g.upscale_method != KP2D_UP_CONVTRANSPOSE &&
-                      m->precision == KP2D_PREC_F16X3 && m->multi_launch && !P.no_levels &&
+                      m->precision == KP2D_PREC_F16X3 && m->multi_launch && !P.no_levels && !s16_all &&
                       (P.dry || (!m->profiling && !m->tap_dst));
   if (levels) {
     const std::string L = "seg_head.convs.";
@@ -1156,7 +1206,8 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.conv("desc_head.upsample", db, db.C, 0, nullptr, lk, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
       P.release(db);
     } else {
-      P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
+      if (s16_all) d2.fmt = 1;
+      P.conv("desc_head.convB", d1, d1.C, 0, nullptr, ACT_NONE, s16_all ? ST_S16P_SHUFFLE : ST_SHUFFLE, P.dry ? nullptr : P.ptr(d2), d2.C, 0, nullptr, 0, 0, 0, Hc, Wc);
     }
     P.release(d1);
     P.tap("desc_head.convB", d2);     // the pixel-shuffled / transposed-conv upsampled tensor (heads.py:96-98)
@@ -1171,7 +1222,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // CBR(ch -> d1) + 2x upsampling: PixelShuffle folded into the store, or (to_mcu) the CBR at its own resolution
   // followed by TransposedConvUpsampleModel as a second, pixel-shuffled conv (segmentation.py:139-147)
   auto upconv = [&](const std::string& cname, const std::string& uname, const Act& in) -> Act {
-    if (g.upscale_method != KP2D_UP_CONVTRANSPOSE) return P.cbr(cname, in, nullptr, ST_SHUFFLE);
+    if (g.upscale_method != KP2D_UP_CONVTRANSPOSE) return P.cbr(cname, in, nullptr, s16_all ? ST_S16P_SHUFFLE : ST_SHUFFLE);
     Act t = P.cbr(cname, in, nullptr, ST_NHWC);
     Act u = P.cbr(uname, t, nullptr, ST_SHUFFLE);
     P.release(t);
@@ -1202,7 +1253,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
       P.release(g2);
       Act g4 = upconv(L + "4", hp + ".upsample", g3);
       P.release(g3);
-      g5 = P.cbr(L + "5", g4, &xb, ST_NHWC);
+      g5 = P.cbr(L + "5", g4, &xb, s16_all ? ST_S16P : ST_NHWC);
       P.release(g4);
       i = 6;
     }
@@ -1239,7 +1290,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   // ---- VPR head (vpr.py:78-89) + NetVLAD (netvlad.py:79-106) ----
   {
     Act v1 = first("vlad_head.convlad1");
-    Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, ST_NHWC);
+    Act v2 = P.cbr("vlad_head.convlad2", v1, nullptr, s16_all ? ST_S16P : ST_NHWC);
     P.release(v1);
     Act v3a = P.cbr("vlad_head.convlad3", v2, nullptr, ST_NHWC);
     P.release(v2);
@@ -1247,6 +1298,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(v3a);
   }
   if (merged) P.release(mx);
+  if (merged) P.release(mxs);
   P.release(xb);
   P.release(skip);
 }
@@ -1789,6 +1841,12 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "stem_fusion") {       // 1 (default): conv1a in split-fp16 products, inside conv1b's launch on big grids; 2: never fused; 0: exact-fp32 FMA kernels
     if (value < 0 || value > 2) return fail(KP2D_ERR_ARG, "stem_fusion is 0, 1 or 2");
     m->stem_fusion = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "s16_all") {      // 1 (default): S16P tensors between the warp-specialised 3x3 layers of big grids; 0: only inside the 32-channel stage
+    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "s16_all is 0 or 1");
+    m->s16_all = value != 0;
+    m->plan_cache.clear();
     return KP2D_OK;
   }
   if (k == "multi_launch") {      // 1 (default): layers of different heads that wait for the same predecessor run as one launch on small grids

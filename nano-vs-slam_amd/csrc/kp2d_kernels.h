@@ -26,11 +26,17 @@ enum Store : int {
   ST_NCHW = 4,             // API-facing planar output; channels [0,nsplit) -> out0, [nsplit,cout) -> out1
   ST_S16P = 5,             // out0 is an S16P tensor (below), full resolution
   ST_S16P_POOL = 6,        // out1 = MaxPool2d(2,2) of the activation as an S16P tensor (conv1b)
+  ST_S16P_BOTH = 7,        // out0 full-res AND out1 pooled, both S16P tensors (conv3b: skip + x)
+  ST_S16P_SHUFFLE = 8,     // PixelShuffle(2) folded into the store, out0 the 2H x 2W S16P tensor (cout / 4 a multiple of 32)
+  ST_MIX16 = 9,            // 64-channel groups below channel `nsplit`: fp32 NHWC into out0 (os0 channels); from `nsplit` on: the
+                           // S16P tensor out1 (os1 channels, its chunk 0 = channel nsplit) — the heads' merged first layer, whose
+                           // score / location slices are read by the fp32 dot-product kernels and the rest by split-fp16 convs
 };
 // S16P ("split, planar rows"): an activation kept as the fp16 halves the split-fp16 kernels multiply, x = hi + lo with
 // hi = fp16(x), lo = fp16(x - hi) — per frame [C / 16 chunks][H][plane: hi | lo][W][16 halves], the same bytes as fp32 NHWC.
 // A tile row of one plane is contiguous, so the consumer copies its LDS operand image straight from HBM (conv3x3_s16.hip).
-// Only between layers of one forward (workspace tensors of the backbone's 32-channel stage); C a multiple of 16.
+// Only between layers of one forward (workspace tensors); C a multiple of 16.  Readers: conv3x3_s16.hip (32 input channels, the
+// layer's weights resident in LDS) and conv3x3_wsm.hip's IN16 form (any whole number of chunks, one or two S16P sources).
 
 // One 3x3 / stride 1 / pad 1 (taps = 9) or 1x1 (taps = 1) convolution over an NHWC activation that may be
 // the channel-concat of two tensors (torch.cat([up, skip], 1): heads.py:99, segmentation.py:141,149).
@@ -62,6 +68,7 @@ struct ConvArgs {
   // conv1a's weights [27][16] / folded BatchNorm; in0 is then unused.  nullptr: conv1a is its own launch
   const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_shift; const float* stem_wscale; int stem_act;   // stem_wscale: device pointer to 2^e
   int s16_min;                        // conv3x3_s16.hip: least work items for the form (0: automatic, three rounds per workgroup)
+  int wsm_force;                      // the plan fixed this layer's tensor layouts on conv3x3_wsm.hip running it (S16P in or out): no item-count policy
   int dbg;                            // timing ablations only (KP2D_DBG): 1 skip the epilogue, 2 skip LDS commit, 4 skip global loads, 8 skip MFMA, 64 skip only the epilogue's global stores
 };
 
@@ -95,7 +102,10 @@ int launch_conv3x3_f16x3_s16(const ConvArgs& a, hipStream_t s);
 bool conv3x3_s16_would_run(int B, int H, int W, int lanes, int min_items, int grid_opt);
 // would the warp-specialised conv1b form (conv3x3_f16.hip, the only producer of a pooled S16P tensor) run
 bool conv3x3_ws_would_run(int B, int H, int W, int ws_min);
-int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);   // kp2d_set_tap on an S16P tensor
+// kp2d_set_tap on an S16P tensor: channels [c0, c0 + C) of a Ct-channel tensor -> planar fp32
+int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Ct, int c0, hipStream_t s);
+// would conv3x3_wsm.hip's automatic policy take a 64-channel-group layer of `groups` groups on a B x H x W map
+bool conv3x3_wsm_would_run(int B, int H, int W, int groups, int lanes, int wsm_min, int grid_opt);
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {

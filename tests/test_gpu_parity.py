@@ -1172,6 +1172,74 @@ def test_split_activation_backbone_stage_equals_the_fp32_activation_path(config,
             assert bool(((r - g).abs() <= 3e-7 * r.abs() + 1.2e-7).all()), (t, float((r - g).abs().max()))
 
 
+def _set_opt(model, key, value):
+    eng = model._engine
+    assert eng.lib.kp2d_set_option(eng.handle, key.encode(), value) == 0
+
+
+# layers of KP2DTiny-S whose tensors change layout with s16_all: (tap, channels, downsampling of the tapped tensor)
+_S16ALL_TAPS = [("backbone.conv3b", 64, 2), ("backbone.conv4a", 64, 4), ("backbone.conv4b", 64, 4), ("score_head.convDa", 64, 4),
+                ("desc_head.convA", 64, 4), ("seg_head.convs.0", 64, 4), ("vlad_head.convlad1", 64, 4), ("desc_head.convB", 32, 2),
+                ("desc_head.confAa", 64, 2), ("seg_head.convs.1", 64, 8), ("seg_head.convs.4", 32, 4), ("seg_head.convs.5", 64, 4),
+                ("seg_head.convs.6", 32, 2), ("seg_head.convs.7", 64, 2), ("vlad_head.convlad2", 64, 4), ("vlad_head.convlad3", 64, 4)]
+
+
+@pytest.mark.parametrize("B,H,W,forced", [
+    # 48 frames of 240 x 320 with two stream lanes: the automatic policy (conv4a = 576 items on 128 workgroups); forced:
+    # 272 x 320 -> conv4a's map 68 x 80 = ragged tile rows (4.25) AND columns (2.5), convs.4's 34 x 40 (the layout needs the
+    # merged first layer: a cell grid of at least 60 x 80, or a small grid); 96 x 256 -> the least width the layout takes
+    # (convs.4 reads a 12 x 32 map), one tile row with 12 of its 16 rows, few frames
+    (48, 240, 320, False),
+    (12, 272, 320, True),
+    (5, 96, 256, True),
+])
+def test_all_split_activations_equal_the_fp32_activation_layout(B, H, W, forced):
+    """Big grids keep EVERY tensor a warp-specialised split-fp16 3x3 layer reads as S16P (kp2d_api.cpp build(): conv3b's two
+    outputs, conv4a / 4b, the desc / seg / vlad slices of the merged first layer, both pixel-shuffled tensors, convs.5,
+    convlad2), copied into LDS by LDS-DMA (conv3x3_wsm.hip IN16) — against the same forward with s16_all = 0: every
+    consumer multiplies the halves its own staging would have produced, so every OUTPUT is bit-identical; the profile says
+    which form ran; a tap of a split tensor (hi + lo) equals the fp32 activation to two units in the last place, a tap of
+    a tensor that stays fp32 (score slice, confAa, convs.1, convs.7, convlad3) bit for bit."""
+    model, _ = product_model("S", False, 28)
+    x = torch.from_numpy(synthetic_frames(B, H, W, seed=57)).to(DEV)
+    fp32_taps = {"score_head.convDa", "desc_head.confAa", "seg_head.convs.1", "seg_head.convs.7", "vlad_head.convlad3"}
+    with torch.no_grad():
+        model(x[:1])
+        if forced:
+            _set_s16(model, 1, 1)
+            _set_wsm(model, 1)
+            _set_opt(model, "lanes", 1)      # (two lanes halve the few frames: below the form's least grid, the layout stays fp32)
+        res = {}
+        for mode in (0, 1):
+            _set_opt(model, "s16_all", mode)
+            ran = _kernels_that_ran(model, x)
+            out = {k: v.clone() for k, v in model(x).items()}
+            taps = {t: model.forward_with_tap(x, t, (c, H // d, W // d))[1].clone() for t, c, d in _S16ALL_TAPS}
+            res[mode] = (ran, out, taps)
+        _set_opt(model, "s16_all", 1)
+        _set_opt(model, "lanes", 0)
+        _set_s16(model, 0, 0)
+        _set_wsm(model, 0)
+    ran_off, ref, ref_t = res[0]
+    ran_on, got, got_t = res[1]
+    assert not any("s16i" in k or "s16out" in k for ks in ran_off.values() for k in ks), ran_off
+    for layer, form in [("backbone.conv4a", "s16io"), ("backbone.conv4b", "s16io"), ("heads.first", "s16io"), ("desc_head.convB", "s16io"),
+                        ("desc_head.confAa", "s16in"), ("seg_head.convs.1", "s16in"), ("seg_head.convs.4", "s16out"),
+                        ("seg_head.convs.5", "s16io"), ("seg_head.convs.6", "s16io"), ("seg_head.convs.7", "s16in"),
+                        ("vlad_head.convlad2", "s16io"), ("vlad_head.convlad3", "s16in")]:
+        assert any("<wsm>" + form in k for k in ran_on[layer]), (layer, ran_on[layer])
+    assert any("<s16>" in k for k in ran_on["backbone.conv3b"]), ran_on["backbone.conv3b"]
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()))
+    for t, _, _ in _S16ALL_TAPS:
+        r, g = ref_t[t], got_t[t]
+        assert r.shape == g.shape and not bool(torch.isnan(g).any()), t
+        if t in fp32_taps:
+            assert torch.equal(r, g), t
+        else:
+            assert bool(((r - g).abs() <= 3e-7 * r.abs() + 1.2e-7).all()), (t, float((r - g).abs().max()))
+
+
 @pytest.mark.parametrize("precision,form", [("f16x3", "auto"), ("f16x3", "general"), ("fp32", "auto")])
 def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(precision, form):
     """The fast tile forms need big launches (ws >= 1024 tiles, wsm >= 256 items, <1,2,16> >= 1024 wide tiles, flat32 >= 512)
@@ -1211,6 +1279,7 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
         # (32-channel items of the register-staging persistent form measured slower)
         if form == "auto":
             assert any("<ws>" in k and "s16" in k for k in ran["backbone.conv1b"]), ran["backbone.conv1b"]
+            assert any("<wsm>s16io" in k for k in ran["backbone.conv4a"]), ran["backbone.conv4a"]      # S16P beyond the 32-channel stage
             for layer in ("backbone.conv2a", "backbone.conv2b", "backbone.conv3a", "backbone.conv3b"):
                 assert any("<s16>" in k for k in ran[layer]), (layer, ran[layer])
         else:

@@ -1,9 +1,13 @@
 #!/bin/bash
 # Regenerate everything under profiles/ that is quoted in DESIGN.md, in one GPU-box session:
-#   tools/refresh_profiles.sh [outdir]      (default gpurun_out/refresh; copy the results into profiles/ as r<round>_* afterwards)
+#   tools/refresh_profiles.sh [outdir] [part]      (default gpurun_out/refresh; copy the results into profiles/ as r<round>_* afterwards)
+# part: all (default) | timed (bench lines, sweep, LightGlue, front-end) | prof (rocprofv3 stats, per-layer tables) | pmc — a gpurun call
+# is limited to 20 minutes, the whole script takes longer
 # Steps are joined so that a failing GPU step stops the script (no GPU step runs after a timeout).
 set -eu -o pipefail
 OUT=${1:-gpurun_out/refresh}
+PART=${2:-all}
+want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "[refresh] $*"; }
@@ -11,6 +15,7 @@ step() { echo "[refresh] $*"; }
 ERRN=0
 errf() { ERRN=$((ERRN + 1)); echo "$OUT/step_${ERRN}.err"; }
 
+if want timed; then
 step "bench line"
 timeout -k 10 300 python3 bench.py 2>"$(errf)" | tail -1 > "$OUT/bench.json"
 timeout -k 10 300 python3 bench.py --steps 1000 --no-cpu-baseline --no-precision-modes 2>"$(errf)" | tail -1 > "$OUT/bench_sustained_1000steps.json"
@@ -45,6 +50,8 @@ timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 --match
 timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 2000 --match --semantic 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 timeout -k 10 200 python3 tools/bench_frontend.py --batch 1 --steps 1000 --lightglue --top-k-matches 200 2>"$(errf)" | tail -1 >> "$OUT/frontend.jsonl"
 cut -c1-200 "$OUT/frontend.jsonl"
+fi
+if want prof; then
 step "rocprofv3 kernel stats, the default bench command (two steps in flight: kernels of the two streams overlap, durations are wall time under sharing)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o r -- python3 bench.py --no-cpu-baseline --no-precision-modes > "$OUT/stats2.log" 2>&1
 step "rocprofv3 kernel stats, one step at a time on a single lane (nothing overlaps: the launch shape of bench.py's HIP-event figures)"
@@ -58,6 +65,8 @@ timeout -k 10 200 python3 tools/layer_profile.py --batch 32 > "$OUT/layers_32fra
 timeout -k 10 200 python3 tools/layer_profile.py --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32 > "$OUT/layers_cfg4.txt" 2>"$(errf)"
 timeout -k 10 200 python3 tools/layer_profile.py --batch 1 --reps 20 > "$OUT/layers_1frame.txt" 2>"$(errf)"
 
+fi
+if want pmc; then
 step "PMC passes"
 tools/pmc_collect.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
 python3 tools/pmc_summarize.py "$OUT/pmc" > "$OUT/pmc_summary.txt" 2>"$(errf)"
@@ -65,5 +74,6 @@ python3 tools/pmc_traffic.py "$OUT/pmc" "$OUT/traffic.json" > /dev/null 2>"$(err
 tools/pmc_collect.sh "$OUT/pmc_cfg4" --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32 > "$OUT/pmc_cfg4.log" 2>&1
 python3 tools/pmc_summarize.py "$OUT/pmc_cfg4" > "$OUT/pmc_cfg4_summary.txt" 2>"$(errf)"
 find "$OUT/pmc" "$OUT/pmc_cfg4" -name "*.csv" -delete      # only the summaries are kept
+fi
 
 step done
