@@ -1075,7 +1075,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, hipStream_t s) {
   if (a.taps != 9 || a.prec != 1) return -1000;
   // S16P tensors (kp2d_kernels.h): read by conv3x3_s16.hip (32 input channels) and by conv3x3_wsm.hip's IN16 form, written by
   // both and by the conv1b form below.  No other kernel takes the layout: -1006 is a plan bug
-  if (a.in0.fmt == 1 && a.cin == 32 && a.in1.c == 0) return launch_conv3x3_f16x3_s16(a, s);
+  if (a.in0.fmt == 1 && a.in1.c == 0 && (a.cin == 32 || a.store == ST_NCHW)) return launch_conv3x3_f16x3_s16(a, s);
   if (a.wsm_force) {
     const int e = launch_conv3x3_f16x3_wsm(a, s, 64);
     return e == -1000 ? -1006 : e;

@@ -45,16 +45,16 @@ constexpr int D_LO = D_ROWS * D_PITCH * D_PXB;         // byte offset of an imag
 constexpr int D_IMG = 2 * D_LO;                        // one input image: hi plane | lo plane (41,472 B)
 constexpr int D_NPIECE = (D_IMG + 1023) / 1024;        // 1-KiB LDS-DMA pieces of an image (41: the last one is half a piece)
 constexpr int D_PW = (D_NPIECE + 3) / 4;               // pieces per DMA wave and step (11; 44 slots: three duplicates)
-constexpr int D_NCH = 2;                               // 16-channel chunks of the input (cin = 32)
 constexpr int D_MAXC = 64;                             // output channels (scale / shift vectors in LDS)
+// nch = 16-channel chunks of the input: 2 (cin = 32: conv2a .. conv3b) or 4 (cin = 64 -> 32 planar output channels: confBb, convs.8)
 __host__ __device__ constexpr int d_wl(int n) { return 9 * n * 32; }                  // byte offset of the wl plane behind the wh plane
 __host__ __device__ constexpr int d_wslab(int n) { return 2 * d_wl(n); }              // a chunk's weight slab (18,432 / 36,864 B)
-__host__ __device__ constexpr int d_nimg(int n) { return n == 32 ? 3 : 2; }           // image stages
-__host__ __device__ constexpr int d_wbase(int n) { return d_nimg(n) * D_IMG; }        // weights behind the images
-__host__ __device__ constexpr int d_ss(int n) { return d_wbase(n) + D_NCH * d_wslab(n); }
-__host__ __device__ constexpr int d_lds(int n) { return d_ss(n) + 2 * D_MAXC * 4; }   // 161,792 / 157,184 B
+__host__ __device__ constexpr int d_nimg(int n, int nch) { return n * nch == 64 ? 3 : 2; }      // image stages beside the resident weights
+__host__ __device__ constexpr int d_wbase(int n, int nch) { return d_nimg(n, nch) * D_IMG; }  // weights behind the images
+__host__ __device__ constexpr int d_ss(int n, int nch) { return d_wbase(n, nch) + nch * d_wslab(n); }
+__host__ __device__ constexpr int d_lds(int n, int nch) { return d_ss(n, nch) + 2 * D_MAXC * 4; }   // 161,792 / 157,184 / 157,184 B
 constexpr int D_THREADS = 768;
-static_assert(d_lds(32) <= 160 * 1024 && d_lds(64) <= 160 * 1024, "LDS budget");
+static_assert(d_lds(32, 2) <= 160 * 1024 && d_lds(64, 2) <= 160 * 1024 && d_lds(32, 4) <= 160 * 1024, "LDS budget");
 static_assert(D_NPIECE == 41 && D_IMG - 1024 * (D_NPIECE - 1) == 512, "the last piece is its first 32 lanes");
 
 __host__ __device__ constexpr int d_slot_tap(int s) { return s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 2 : s; }
@@ -62,12 +62,19 @@ __host__ __device__ constexpr int d_slot_tap(int s) { return s == 2 ? 3 : s == 3
 struct S16Item { int b, y0, x0; };
 }  // namespace
 
-// STORE: ST_S16P (NN = 2) or ST_NHWC / ST_NHWC_POOL / ST_NHWC_BOTH (NN = 4).  One channel group: cout <= 16 NN.
-template <int STORE, int NN>
+// STORE: ST_S16P (NN = 2), ST_NHWC / ST_NHWC_POOL / ST_NHWC_BOTH / ST_S16P_BOTH (NN = 4), or ST_NCHW (NN = 2, D_NCH = 4: the
+// planar API outputs behind a 64-channel S16P tensor).  One channel group: cout <= 16 NN.
+// ST_NCHW multiplies UN-transposed (pixels are the A operand, an M-tile is 1 row x 16 columns): a lane's four accumulator
+// registers of a tile are four consecutive PIXELS of one channel — a 16-byte store into the channel plane, the four lane
+// groups of a tile 64 contiguous bytes, no transposition through LDS.  Each output element is the same sum of the same
+// products in the same order as in the transposed tiles (an MFMA's dot products do not know which operand is called A).
+template <int STORE, int NN, int D_NCH>
 __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const ConvArgs a, const int nitems) {
-  constexpr int D_N = 16 * NN, D_WL = d_wl(D_N), D_WSLAB = d_wslab(D_N), D_NIMG = d_nimg(D_N), D_WB = d_wbase(D_N), D_SS = d_ss(D_N);
-  static_assert(STORE == ST_S16P ? NN == 2 : NN == 4, "32 output channels: S16P only; 64: fp32 forms or S16P full + pooled");
+  constexpr int D_N = 16 * NN, D_WL = d_wl(D_N), D_WSLAB = d_wslab(D_N), D_NIMG = d_nimg(D_N, D_NCH), D_WB = d_wbase(D_N, D_NCH), D_SS = d_ss(D_N, D_NCH);
+  static_assert((STORE == ST_S16P || STORE == ST_NCHW) ? NN == 2 : NN == 4, "32 output channels: S16P or planar; 64: fp32 forms or S16P full + pooled");
+  static_assert(D_NCH == (STORE == ST_NCHW ? 4 : 2), "64 input channels: the planar form only");
   constexpr bool S16OUT = STORE == ST_S16P || STORE == ST_S16P_BOTH;
+  constexpr bool PLANAR = STORE == ST_NCHW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const sm = reinterpret_cast<char*>(smem);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // FP16_OVFL: conversions that overflow clamp to +-65504
@@ -220,7 +227,9 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
   constexpr int MT = 4, CB = 2;
   const int lg = lane >> 4, lp = lane & 15;
   const int ph = wave >> 2, wr = (wave + 2 * ph) & 3;
-  const int a0 = ((wr * 4 + ((lp >> 1) & 1)) * D_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * D_PXB + 16 * (lg & 1);
+  // (PLANAR: M-tile m = row 4 wr + m, columns 16 ph .. + 15, lane lp = column; else 2 x 8 pixel M-tiles, pooling quads in 4 lanes)
+  const int a0 = PLANAR ? ((wr * 4) * D_PITCH + 16 * ph + lp) * D_PXB + 16 * (lg & 1)
+                        : ((wr * 4 + ((lp >> 1) & 1)) * D_PITCH + 16 * ph + 2 * (lp >> 2) + (lp & 1)) * D_PXB + 16 * (lg & 1);
   const int a_dx = a0 + (lg >> 1) * D_PXB;                 // second tap one pixel to the right
   const int a_dy = a0 + (lg >> 1) * D_PITCH * D_PXB;       // second tap one row down
   const int a_s = a0 + (lg >> 1) * D_LO;                   // single tap: k-groups 2, 3 read the lo plane
@@ -253,22 +262,25 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int mo = (2 * (m / CB) * D_PITCH + 8 * (m % CB)) * D_PXB;
+        const int mo = PLANAR ? m * D_PITCH * D_PXB : (2 * (m / CB) * D_PITCH + 8 * (m % CB)) * D_PXB;
+        auto mma = [&](const f16x8 w, const f16x8 x, const f32x4 c) -> f32x4 {      // weights x pixels, or (PLANAR) pixels x weights
+          return PLANAR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(x, w, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
+        };
         if (single) {
           const f16x8 x = *reinterpret_cast<const f16x8*>(sm + ab + mo);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], x, acc[m][n], 0, 0, 0);
+            acc[m][n] = mma(bl[n], x, acc[m][n]);
+            acc[m][n] = mma(bh[n], x, acc[m][n]);
           }
         } else {
           const f16x8 zh = *reinterpret_cast<const f16x8*>(sm + ab + mo);
           const f16x8 zl = *reinterpret_cast<const f16x8*>(sm + ab + mo + D_LO);
 #pragma unroll
           for (int n = 0; n < NN; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh, acc[m][n], 0, 0, 0);
+            acc[m][n] = mma(bh[n], zl, acc[m][n]);
+            acc[m][n] = mma(bl[n], zh, acc[m][n]);
+            acc[m][n] = mma(bh[n], zh, acc[m][n]);
           }
         }
       }
@@ -290,7 +302,30 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
   };
   auto finish = [&](const S16Item& it) {
     const int prow = (lp >> 1) & 1, pcol = 2 * (lp >> 2) + (lp & 1);      // this lane's pixel inside a 2 x 8 M-tile
-    if constexpr (S16OUT) {
+    if constexpr (PLANAR) {
+      // tile (m, n): lane (lp, lg) holds channel 16 n + lp, pixels (row 4 wr + m, columns 16 ph + 4 lg .. + 3).  Plain logits
+      // (no activation), every channel into out0 [B, cout, H, W]; W is a multiple of 4, so a lane's four pixels are inside or
+      // outside the map together.  (Not for a layer that also writes the dense class map, ConvArgs::ids_out: its channels sit
+      // in 32 different lanes here, and the argmax by DPP rotations cost more than the form gains — kp2d_api.cpp s16_planar)
+      const int obs = a.cout * H * W;
+      const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.out0 + (size_t)it.b * obs, 0, obs * 4, 0x00020000);
+      const int x = it.x0 + 16 * ph + 4 * lg;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int y = it.y0 + wr * 4 + m;
+        const int inv = (y < H && x < W) ? 0 : OOB;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+          const int c = 16 * n + lp;
+          const float sc = smem[D_SS / 4 + c], sh = smem[D_SS / 4 + D_MAXC + c];
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[m][n][r], sc, sh);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs0,
+                                                 KP2D_DBG_ON(64) ? OOB : ((((c * H + y) * W + x) * 4) | inv | (c < a.cout ? 0 : OOB)), 0, 0);
+        }
+      }
+    } else if constexpr (S16OUT) {
       // per N-tile pair p: lane group lg holds channels 32 p + 8 lg .. + 7 of its pixel (tiles 2 p, 2 p + 1): chunk
       // 2 p + (lg >> 1), halves 8 (lg & 1) .. + 7.  ST_S16P_BOTH (conv3b): also the 2 x 2 maximum, as a second S16P tensor
       constexpr bool both = store == ST_S16P_BOTH;
@@ -427,7 +462,14 @@ __global__ __launch_bounds__(D_THREADS, 3) void conv3x3_f16x3_s16_kernel(const C
 
 // ---- launch side -----------------------------------------------------------------------------------------------------
 static bool s16_eligible(const ConvArgs& a) {
-  if (a.taps != 9 || a.prec != 1 || a.in0.fmt != 1 || a.in1.c != 0 || a.cin != 16 * D_NCH || a.in0.c != a.cin) return false;
+  if (a.taps != 9 || a.prec != 1 || a.in0.fmt != 1 || a.in1.c != 0 || a.in0.c != a.cin || a.in0.o != 0) return false;
+  if (a.store == ST_NCHW) {
+    // planar logits behind a 64-channel S16P tensor (confBb, convs.8): one 32-channel group, every channel into out0
+    if (a.cin != 64 || a.npad != 32 || a.act != ACT_NONE || a.nsplit != a.cout || a.W < 32 || (a.W & 3) || a.ids_out) return false;
+    if (a.in0.bs != (long)a.H * a.W * a.cin || (long)a.H * a.W * a.cin * 4 >= 0x7ffffff0L) return false;
+    return true;
+  }
+  if (a.cin != 32) return false;
   if (a.act > ACT_RELU || a.W < 32 || (a.cout & 15)) return false;
   if (a.store == ST_S16P) { if (a.npad != 32) return false; }
   else if (a.store == ST_NHWC || a.store == ST_NHWC_POOL || a.store == ST_NHWC_BOTH || a.store == ST_S16P_BOTH) { if (a.npad != 64) return false; }
@@ -470,11 +512,11 @@ bool conv3x3_s16_would_run(int B, int H, int W, int lanes, int min_items, int gr
   return s16_grid(nitems, lanes, min_items, grid_opt) > 0;
 }
 
-template <int STORE, int NN>
+template <int STORE, int NN, int NCH = 2>
 static int s16_launch_one(const ConvArgs& a, int grid, long nitems, hipStream_t s) {
   static PerDeviceOnce lds_once;      // per instantiation and device
-  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_s16_kernel<STORE, NN>))) return e;
-  hipLaunchKernelGGL((conv3x3_f16x3_s16_kernel<STORE, NN>), dim3(grid), dim3(D_THREADS), d_lds(16 * NN), s, a, (int)nitems);
+  if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_s16_kernel<STORE, NN, NCH>))) return e;
+  hipLaunchKernelGGL((conv3x3_f16x3_s16_kernel<STORE, NN, NCH>), dim3(grid), dim3(D_THREADS), d_lds(16 * NN, NCH), s, a, (int)nitems);
   return (int)hipGetLastError();
 }
 
@@ -489,8 +531,9 @@ int launch_conv3x3_f16x3_s16(const ConvArgs& a0, hipStream_t s) {
   const long nitems = (long)a.tiles_x * a.tiles_y * a.B;
   const int grid = s16_grid(nitems, a.wsm_lanes, a.s16_min, a.wsm_grid);
   if (grid == 0) return -1006;
-  conv3x3_note_variant("<s16>");
+  conv3x3_note_variant(a.store == ST_NCHW ? "<s16>planar" : "<s16>");
   switch (a.store) {
+    case ST_NCHW: return s16_launch_one<ST_NCHW, 2, 4>(a, grid, nitems, s);
     case ST_S16P: return s16_launch_one<ST_S16P, 2>(a, grid, nitems, s);
     case ST_NHWC: return s16_launch_one<ST_NHWC, 4>(a, grid, nitems, s);
     case ST_NHWC_BOTH: return s16_launch_one<ST_NHWC_BOTH, 4>(a, grid, nitems, s);

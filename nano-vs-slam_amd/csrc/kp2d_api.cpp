@@ -710,7 +710,7 @@ struct Plan {
     a.s16_min = m->s16_min;
     // S16P tensors beyond the 32-channel stage are read and written by conv3x3_wsm.hip only: build() fixed the layout
     // after asking conv3x3_wsm_would_run, the launcher then skips its item-count policy
-    a.wsm_force = ((s0.fmt == 1 && !(c.cin == 32 && s1.c == 0)) || store == ST_S16P_SHUFFLE || store == ST_MIX16 ||
+    a.wsm_force = ((s0.fmt == 1 && !(c.cin == 32 && s1.c == 0) && store != ST_NCHW) || store == ST_S16P_SHUFFLE || store == ST_MIX16 ||
                    (store == ST_S16P && c.npad >= 64)) ? 1 : 0;
     if (stem_x && name == "backbone.conv1b") {
       a.stem_x = stem_x; a.stem_w = m->blob + m->conv1a_w; a.stem_scale = m->blob + m->conv1a_sc; a.stem_shift = m->blob + m->conv1a_sh;
@@ -1054,6 +1054,13 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   const int H2 = skip.H, W2 = skip.W;
   if (xb.H != Hc || xb.W != Wc) { P.rc = fail(KP2D_ERR_ARG, "plan: cell grid %dx%d, expected %dx%d", xb.H, xb.W, Hc, Wc); return; }
 
+  // the two planar outputs behind a 64-channel S16P tensor (conv3x3_s16.hip's planar form: cout <= 32 plain logits)
+  static const bool planar_env = !(getenv("KP2D_S16PLANAR") && getenv("KP2D_S16PLANAR")[0] == '0');      // (A/B knob)
+  // (not the class logits when the forward also writes the dense class map: the argmax over channels that sit in 32 different
+  // lanes — DPP rotations per pixel — made that layer 0.147 -> 0.189 ms; the general kernel finds it in its LDS tile)
+  auto s16_planar = [&](int cout, bool with_ids = false) {
+    return s16_all && planar_env && !with_ids && cout <= 32 && m->c4 == 64 && m->c5 == 64 && !(W2 & 3);
+  };
   Act mx{}, mxs{};
   int mx_split = 1 << 30;      // first channel of the merged layer kept in the S16P tensor mxs (s16_all: behind score | loc)
   if (merged && s16_all) {
@@ -1211,7 +1218,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     }
     P.release(d1);
     P.tap("desc_head.convB", d2);     // the pixel-shuffled / transposed-conv upsampled tensor (heads.py:96-98)
-    Act d3 = P.cbr("desc_head.confAa", d2, &skip, ST_NHWC);
+    Act d3 = P.cbr("desc_head.confAa", d2, &skip, s16_planar(g.nfeatures) ? ST_S16P : ST_NHWC);
     P.release(d2);
     P.conv("desc_head.confBb", d3, d3.C, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
     P.release(d3);
@@ -1259,7 +1266,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     }
     Act g6 = upconv(L + std::to_string(i), hp + ".upsample2", g5);
     P.release(g5);
-    Act g7 = P.cbr(L + std::to_string(i + 1), g6, &skip, ST_NHWC);
+    Act g7 = P.cbr(L + std::to_string(i + 1), g6, &skip, (hp == "seg_head" && s16_planar(g.n_classes, P.seg_ids != nullptr)) ? ST_S16P : ST_NHWC);
     P.release(g6);
     *last = L + std::to_string(i + 2);
     return g7;

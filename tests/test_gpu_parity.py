@@ -1196,13 +1196,13 @@ _S16ALL_TAPS = [("backbone.conv3b", 64, 2), ("backbone.conv4a", 64, 4), ("backbo
 def test_all_split_activations_equal_the_fp32_activation_layout(B, H, W, forced):
     """Big grids keep EVERY tensor a warp-specialised split-fp16 3x3 layer reads as S16P (kp2d_api.cpp build(): conv3b's two
     outputs, conv4a / 4b, the desc / seg / vlad slices of the merged first layer, both pixel-shuffled tensors, convs.5,
-    convlad2), copied into LDS by LDS-DMA (conv3x3_wsm.hip IN16) — against the same forward with s16_all = 0: every
+    convlad2, confAa's and convs.7's outputs), copied into LDS by LDS-DMA (conv3x3_wsm.hip IN16, conv3x3_s16.hip) — against the same forward with s16_all = 0: every
     consumer multiplies the halves its own staging would have produced, so every OUTPUT is bit-identical; the profile says
     which form ran; a tap of a split tensor (hi + lo) equals the fp32 activation to two units in the last place, a tap of
-    a tensor that stays fp32 (score slice, confAa, convs.1, convs.7, convlad3) bit for bit."""
+    a tensor that stays fp32 (score slice, convs.1, convlad3) bit for bit."""
     model, _ = product_model("S", False, 28)
     x = torch.from_numpy(synthetic_frames(B, H, W, seed=57)).to(DEV)
-    fp32_taps = {"score_head.convDa", "desc_head.confAa", "seg_head.convs.1", "seg_head.convs.7", "vlad_head.convlad3"}
+    fp32_taps = {"score_head.convDa", "seg_head.convs.1", "vlad_head.convlad3"}      # (convs.7: either, by the class-map rule below)
     with torch.no_grad():
         model(x[:1])
         if forced:
@@ -1224,11 +1224,15 @@ def test_all_split_activations_equal_the_fp32_activation_layout(B, H, W, forced)
     ran_on, got, got_t = res[1]
     assert not any("s16i" in k or "s16out" in k for ks in ran_off.values() for k in ks), ran_off
     for layer, form in [("backbone.conv4a", "s16io"), ("backbone.conv4b", "s16io"), ("heads.first", "s16io"), ("desc_head.convB", "s16io"),
-                        ("desc_head.confAa", "s16in"), ("seg_head.convs.1", "s16in"), ("seg_head.convs.4", "s16out"),
-                        ("seg_head.convs.5", "s16io"), ("seg_head.convs.6", "s16io"), ("seg_head.convs.7", "s16in"),
+                        ("desc_head.confAa", "s16io"), ("seg_head.convs.1", "s16in"), ("seg_head.convs.4", "s16out"),
+                        ("seg_head.convs.5", "s16io"), ("seg_head.convs.6", "s16io"), ("seg_head.convs.7", "s16i"),
                         ("vlad_head.convlad2", "s16io"), ("vlad_head.convlad3", "s16in")]:
         assert any("<wsm>" + form in k for k in ran_on[layer]), (layer, ran_on[layer])
     assert any("<s16>" in k for k in ran_on["backbone.conv3b"]), ran_on["backbone.conv3b"]
+    # the descriptor map straight from the accumulators of un-transposed products (conv3x3_s16.hip's planar form); the class
+    # logits too unless the forward also writes the dense class map (then the general kernel, which finds the argmax in LDS)
+    assert any("<s16>planar" in k for k in ran_on["desc_head.confBb"]), ran_on["desc_head.confBb"]
+    assert any("<s16>planar" in k or "flat32" in k or "<1,1," in k for k in ran_on["seg_head.convs.8"]), ran_on["seg_head.convs.8"]
     for k in ref:
         assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()))
     for t, _, _ in _S16ALL_TAPS:
@@ -1274,7 +1278,10 @@ def test_large_grid_tile_forms_against_the_reference_fixture_at_headline_size(pr
                 assert not any("<wsm>t" in k for k in ran[layer]), (layer, ran[layer])      # (the transposed walk is opt-in)
             else:
                 assert any("<2,1,16>" in k or "<2,1,8>" in k for k in ran[layer]), (layer, ran[layer])
-        assert any("flat32" in k for k in forms), forms
+        # the planar outputs: 8 x 32 tiles of the general kernel, or (behind S16P tensors) un-transposed products of conv3x3_s16.hip
+        assert any("flat32" in k or "<s16>planar" in k for k in forms), forms
+        if form == "general":
+            assert any("flat32" in k for k in forms), forms
         # the 32-channel stage: split activations + LDS-DMA staging (conv3x3_s16.hip); with that form off, the wide tiles
         # (32-channel items of the register-staging persistent form measured slower)
         if form == "auto":
