@@ -300,7 +300,7 @@ def test_lds_dma_kernels_compile_without_spills_and_keep_their_copies_in_flight_
 
     with ThreadPoolExecutor(max_workers=2) as ex:
         s16, mff = ex.map(asm_of, ["conv3x3_s16.hip", "mff_tail.hip"])
-    for asm, nk, vmax in ((s16, 6, 168), (mff, 1, 256)):      # (s16: four fp32 / S16P store modes + conv3b's S16P full + pooled + the tap kernel)
+    for asm, nk, vmax in ((s16, 7, 168), (mff, 1, 256)):      # (s16: four fp32 / S16P store modes, conv3b's S16P full + pooled, the planar form, the tap kernel)
         spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
         vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", asm)]
         assert len(spills) == nk and all(v == 0 for v in spills), spills
