@@ -1043,7 +1043,7 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
                        m->wsm_min >= 0 && m->wsm_tr == 0 && merged &&
                        Wq / 2 >= 32 &&      // (convs.4 writes its pixel-shuffled S16P output from a W / 8 map: the form's least width
                        (long)((Wq / 2 + 31) / 32) * ((Hq / 2 + 15) / 16) * B * 2 >= 8 &&      //  and its least grid, eight work items)
-                       conv3x3_wsm_would_run(B, Hq, Wq, 1, P.nlanes, m->wsm_min, m->wsm_grid);
+                       conv3x3_wsm_would_run(B, Hq, Wq, 1, P.nlanes, m->wsm_min, m->wsm_grid, 1);
   Act xp{};
   Act skip = P.cbr("backbone.conv3b", t3a, nullptr, s16_all ? ST_S16P_BOTH : ST_NHWC_BOTH, &xp);   // downsample >= 1 always
   P.release(t3a);

@@ -105,7 +105,7 @@ bool conv3x3_ws_would_run(int B, int H, int W, int ws_min);
 // kp2d_set_tap on an S16P tensor: channels [c0, c0 + C) of a Ct-channel tensor -> planar fp32
 int launch_s16p_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Ct, int c0, hipStream_t s);
 // would conv3x3_wsm.hip's automatic policy take a 64-channel-group layer of `groups` groups on a B x H x W map
-bool conv3x3_wsm_would_run(int B, int H, int W, int groups, int lanes, int wsm_min, int grid_opt);
+bool conv3x3_wsm_would_run(int B, int H, int W, int groups, int lanes, int wsm_min, int grid_opt, int full_rounds);
 
 // ---- NetVLAD (modules/aggregators/netvlad.py:79-106) ---------------------------------------
 struct VladArgs {
