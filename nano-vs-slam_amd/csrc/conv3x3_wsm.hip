@@ -429,67 +429,6 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
       }
     }
   };
-#ifdef KP2D_ABLATE
-  // (timing ablation, KP2D_DBG bit 4: the same MFMA sequence with the operands of the first slot pair read ONCE per step —
-  // what a step costs when no product ever waits for an LDS read.  Bit 128: the reads of every slot, one v_pk_add per
-  // operand instead of the MFMAs — what the LDS side alone costs.)
-  auto multiply_once = [&](int sb) {
-    f16x8 bh[NN], bl[NN], zh[MT], zl[MT];
-#pragma unroll
-    for (int n = 0; n < NN; ++n) {
-      bh[n] = *reinterpret_cast<const f16x8*>(sm + sb + b_p + n * 512);
-      bl[n] = *reinterpret_cast<const f16x8*>(sm + sb + b_p + n * 512 + M_WL);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int mo = (2 * (m / CB) * M_PITCH + 8 * (m % CB)) * M_PXB;
-      zh[m] = *reinterpret_cast<const f16x8*>(sm + sb + a_dx + mo);
-      zl[m] = *reinterpret_cast<const f16x8*>(sm + sb + a_dx + mo + M_LO);
-    }
-#pragma unroll
-    for (int slot = 0; slot < 9; slot += 2) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int n = 0; n < NN; ++n) {
-          if (slot == 8) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh[m], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh[m], acc[m][n], 0, 0, 0);
-          } else {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zl[m], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n], zh[m], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n], zh[m], acc[m][n], 0, 0, 0);
-          }
-        }
-      }
-      asm volatile("" ::: "memory");
-    }
-  };
-  auto multiply_reads = [&](int sb) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 sum = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int slot = 0; slot < 9; slot += 2) {
-      const int tp = m_slot_tap(slot);
-      const bool single = slot == 8;
-      const bool dy = slot == 4;
-      const int ab = sb + (single ? a_s : (dy ? a_dy : a_dx)) + tap_off(tp);
-      const int bb = sb + (single ? b_s : b_p) + slot * M_N * 32;
-#pragma unroll
-      for (int n = 0; n < NN; ++n) {
-        sum += *reinterpret_cast<const h8*>(sm + bb + n * 512);
-        sum += *reinterpret_cast<const h8*>(sm + bb + n * 512 + M_WL);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int mo = (2 * (m / CB) * M_PITCH + 8 * (m % CB)) * M_PXB;
-        sum += *reinterpret_cast<const h8*>(sm + ab + mo);
-        if (!single) sum += *reinterpret_cast<const h8*>(sm + ab + mo + M_LO);
-      }
-    }
-    acc[0][0][0] += (float)sum[0] + (float)sum[1] + (float)sum[2] + (float)sum[3] + (float)sum[4] + (float)sum[5] + (float)sum[6] + (float)sum[7];
-  };
-#endif
   // ---- epilogue.  Accumulator tile (m, n): lane (lp, lg) holds pixel lp of M-tile m, channels 16 n + 4 lg .. + 3 of the
   // item's group.  A lane's byte offset per M-tile (pixel part, padding lanes ORed out of range) is computed once per
   // item; the channel / sub-pixel part of an N-tile is wave-uniform: one scalar added per store.
@@ -659,11 +598,6 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   for (int s = 0; s < nsteps_p; ++s) {
     if (s < nsteps) {
       if (due) { finish(prev); clear(); due = false; }
-#ifdef KP2D_ABLATE
-      if (busy && KP2D_DBG_ON(4)) multiply_once((s & 1) * M_STAGE);
-      else if (busy && KP2D_DBG_ON(128)) multiply_reads((s & 1) * M_STAGE);
-      else
-#endif
       if (busy && !KP2D_DBG_ON(8)) multiply((s & 1) * M_STAGE);
       if (++ch == nchunk) {
         if (busy && !KP2D_DBG_ON(1)) {
