@@ -164,6 +164,10 @@ struct kp2d_model {
   std::vector<hipStream_t> lane_streams;
   std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
+  // single frames (the level schedule of build()): NetVLAD's launches on a side stream beside the segmentation head's chain
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  bool side_overlap = true;   // kp2d_set_option("side_overlap")
   bool profiling = false;
   int64_t* seg_ids_dst = nullptr;   // kp2d_set_seg_ids: class ids [B,1,H2,W2] written by the forward's last segmentation layer
   size_t seg_ids_cap = 0;
@@ -1089,7 +1093,8 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     return P.cbr(name, xb, nullptr, ST_NHWC);
   };
   // NetVLAD / GeM / ConvAP / encoder map behind vlad_head.convlad3 (vpr.py:78-89, netvlad.py:79-106)
-  auto vlad_tail = [&](const Act& v3a) {
+  // (keep: when the tail runs on the side stream its scratch must outlive the plan's next allocations — released by the caller)
+  auto vlad_tail = [&](const Act& v3a, std::vector<Act>* keep = nullptr) {
     const int S = Hc * Wc, K = g.num_clusters, C = g.encoder_dim;
     if (only_enc || g.remove_netvlad) {
       // vpr.py:84-87: remove_netvlad (to_export) returns the encoder map itself whatever the pooler;
@@ -1113,7 +1118,8 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
         P.check(launch_convap_pool(a, P.stream), "vlad_head.netvlad (ConvAP)");
         P.prof_end();
       }
-      P.release(cp);
+      if (keep) keep->push_back(cp);
+      else P.release(cp);
     } else {
       const int ns = netvlad_nsplit(S);
       const int tps = netvlad_tiles_per_slab(S, B);
@@ -1130,7 +1136,8 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
         P.check(launch_netvlad(a, P.stream), "vlad_head.netvlad");
         P.prof_end();
       }
-      P.arena.release(part.off, part.bytes);
+      if (keep) keep->push_back(part);
+      else P.arena.release(part.off, part.bytes);
     }
   };
   // Small grids, the plain V2 configuration (PixelShuffle upsampling, no attention, no depth head): the heads level by
@@ -1165,6 +1172,30 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(d2);
     P.release(g1);
     P.release(v2);
+    // The VPR head is done with its convolutions two launches before the descriptor head and six before the segmentation
+    // head: its pooling (NetVLAD: three launches, ~25 us of a frame's ~230) goes to a side stream and runs BESIDE the rest
+    // (fork / join by events).  Its input and scratch stay allocated until the join (the dry run sizes the workspace the
+    // same way).
+    // Not under stream capture: replayed as graphs with several frames in flight (pipeline.FrameStream) the extra branch
+    // costs the overlap BETWEEN frames — 10.3k -> 4.6k frames/s (profiles/r5_ab_side_stream.txt); a plain forward gains 5 %.
+    std::vector<Act> vlad_keep;
+    bool side = m->side_overlap && m->side_stream && !P.dry && P.rc == KP2D_OK;
+    if (side) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(P.stream, &cs) != hipSuccess) { (void)hipGetLastError(); side = false; }
+      else if (cs != hipStreamCaptureStatusNone) side = false;
+    }
+    hipStream_t main_stream = P.stream;
+    if (side) {
+      P.check((int)hipEventRecord(m->side_fork, main_stream), "side stream fork");
+      P.check((int)hipStreamWaitEvent(m->side_stream, m->side_fork, 0), "side stream fork");
+      P.stream = m->side_stream;
+    }
+    vlad_tail(v3a, &vlad_keep);
+    if (side) {
+      P.check((int)hipEventRecord(m->side_join, m->side_stream), "side stream join");
+      P.stream = main_stream;
+    }
     // level 3
     P.group_begin();
     P.conv("desc_head.confBb", d3, d3.C, 0, nullptr, ACT_NONE, ST_NCHW, o.feat, 0, 0, nullptr, 0, 0, g.nfeatures, H2, W2);
@@ -1172,8 +1203,6 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.group_end();
     P.release(d3);
     P.release(g2);
-    vlad_tail(v3a);
-    P.release(v3a);
     // the rest of the segmentation head is the critical path: one layer per launch
     Act g4 = P.cbr(L + "4", g3, nullptr, ST_SHUFFLE);
     P.release(g3);
@@ -1185,6 +1214,9 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     P.release(g6);
     P.conv(L + "8", g7, g7.C, 0, nullptr, ACT_NONE, ST_NCHW, o.seg, 0, 0, nullptr, 0, 0, g.n_classes, H2, W2);
     P.release(g7);
+    if (side) P.check((int)hipStreamWaitEvent(main_stream, m->side_join, 0), "side stream join");
+    for (const Act& k : vlad_keep) P.arena.release(k.off, k.bytes);
+    P.release(v3a);
     P.release(mx);
     P.release(xb);
     P.release(skip);
@@ -1400,6 +1432,18 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   const char* nlanes = getenv("KP2D_LANES");
   if (nlanes) m->lanes = std::max(1, std::min(8, atoi(nlanes)));
   m->lanes_default = m->lanes;
+  // (created here, not lazily: a forward may run under stream capture, where creating streams is not allowed)
+  if (!(getenv("KP2D_SIDE") && getenv("KP2D_SIDE")[0] == '0')) {
+    DeviceGuard guard(cfg->device);
+    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->side_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->side_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      m->side_overlap = false;
+    }
+  } else {
+    m->side_overlap = false;
+  }
   *out = m;
   return KP2D_OK;
 }
@@ -1411,6 +1455,9 @@ void kp2d_destroy(kp2d_model* m) {
   for (auto st : m->lane_streams) (void)hipStreamDestroy(st);
   for (auto ev : m->lane_events) (void)hipEventDestroy(ev);
   if (m->fork_event) (void)hipEventDestroy(m->fork_event);
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  if (m->side_fork) (void)hipEventDestroy(m->side_fork);
+  if (m->side_join) (void)hipEventDestroy(m->side_join);
   delete m;
 }
 
@@ -1848,6 +1895,11 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   if (k == "stem_fusion") {       // 1 (default): conv1a in split-fp16 products, inside conv1b's launch on big grids; 2: never fused; 0: exact-fp32 FMA kernels
     if (value < 0 || value > 2) return fail(KP2D_ERR_ARG, "stem_fusion is 0, 1 or 2");
     m->stem_fusion = (int)value;
+    return KP2D_OK;
+  }
+  if (k == "side_overlap") {      // 1 (default): single frames run NetVLAD on a side stream beside the segmentation head; 0: in line
+    if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "side_overlap is 0 or 1");
+    m->side_overlap = value != 0 && m->side_stream != nullptr;
     return KP2D_OK;
   }
   if (k == "s16_all") {      // 1 (default): S16P tensors between the warp-specialised 3x3 layers of big grids; 0: only inside the 32-channel stage
