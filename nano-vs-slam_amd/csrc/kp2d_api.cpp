@@ -1179,11 +1179,25 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
     // Not under stream capture: replayed as graphs with several frames in flight (pipeline.FrameStream) the extra branch
     // costs the overlap BETWEEN frames — 10.3k -> 4.6k frames/s (profiles/r5_ab_side_stream.txt); a plain forward gains 5 %.
     std::vector<Act> vlad_keep;
-    bool side = m->side_overlap && m->side_stream && !P.dry && P.rc == KP2D_OK;
+    // The stream is created on first use, not with the model: HIP spreads a process's streams over four hardware queues,
+    // and a stream that exists — used or not — took one from pipeline.BatchStream's two (64-frame batches, two steps in
+    // flight: 25.0k -> 23.6k frames/s with an idle side stream in the process, back at 24.9k with GPU_MAX_HW_QUEUES=8).
+    bool side = m->side_overlap && !P.dry && P.rc == KP2D_OK;
     if (side) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(P.stream, &cs) != hipSuccess) { (void)hipGetLastError(); side = false; }
       else if (cs != hipStreamCaptureStatusNone) side = false;
+    }
+    if (side && !m->side_stream) {
+      if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&m->side_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&m->side_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+        m->side_stream = nullptr;
+        m->side_overlap = false;
+        side = false;
+      }
     }
     hipStream_t main_stream = P.stream;
     if (side) {
@@ -1432,18 +1446,7 @@ int kp2d_create(const kp2d_config* cfg, kp2d_model** out) {
   const char* nlanes = getenv("KP2D_LANES");
   if (nlanes) m->lanes = std::max(1, std::min(8, atoi(nlanes)));
   m->lanes_default = m->lanes;
-  // (created here, not lazily: a forward may run under stream capture, where creating streams is not allowed)
-  if (!(getenv("KP2D_SIDE") && getenv("KP2D_SIDE")[0] == '0')) {
-    DeviceGuard guard(cfg->device);
-    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->side_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->side_join, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      m->side_overlap = false;
-    }
-  } else {
-    m->side_overlap = false;
-  }
+  if (getenv("KP2D_SIDE") && getenv("KP2D_SIDE")[0] == '0') m->side_overlap = false;      // (A/B knob)
   *out = m;
   return KP2D_OK;
 }
@@ -1899,7 +1902,15 @@ int kp2d_set_option(kp2d_model* m, const char* key, long value) {
   }
   if (k == "side_overlap") {      // 1 (default): single frames run NetVLAD on a side stream beside the segmentation head; 0: in line
     if (value < 0 || value > 1) return fail(KP2D_ERR_ARG, "side_overlap is 0 or 1");
-    m->side_overlap = value != 0 && m->side_stream != nullptr;
+    m->side_overlap = value != 0;
+    if (!m->side_overlap && m->side_stream) {      // give the stream (and the hardware queue it maps to) back
+      DeviceGuard guard(m->cfg.device);
+      (void)hipStreamSynchronize(m->side_stream);
+      (void)hipStreamDestroy(m->side_stream);
+      (void)hipEventDestroy(m->side_fork);
+      (void)hipEventDestroy(m->side_join);
+      m->side_stream = nullptr; m->side_fork = m->side_join = nullptr;
+    }
     return KP2D_OK;
   }
   if (k == "s16_all") {      // 1 (default): S16P tensors between the warp-specialised 3x3 layers of big grids; 0: only inside the 32-channel stage

@@ -207,6 +207,11 @@ class FrameStream:
         self._pending = []            # slots in flight, oldest first
         self._next = 0
         self._sig = None
+        # Replayed graphs never use the engine's side stream (kp2d_api.cpp: NetVLAD beside the segmentation head, plain
+        # single-frame forwards only), but a stream that merely EXISTS takes one of the runtime's four hardware queues away
+        # from the slots' streams (10.3k -> 7.4k frames/s, profiles/r5_ab_side_stream.txt): switched off for this model
+        eng = self.net._get_engine(self.dev)
+        _lib.check(eng.lib.kp2d_set_option(eng.handle, b"side_overlap", 0))
         self._capture()
 
     def _step(self, slot):

@@ -1172,6 +1172,26 @@ def test_split_activation_backbone_stage_equals_the_fp32_activation_path(config,
             assert bool(((r - g).abs() <= 3e-7 * r.abs() + 1.2e-7).all()), (t, float((r - g).abs().max()))
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_single_frame_netvlad_on_the_side_stream_equals_in_line(B):
+    """Small grids run the heads level by level; NetVLAD's three launches go to a model-owned side stream beside the
+    segmentation head's chain (kp2d_api.cpp build(): fork after level 2, join before the forward returns; in line under
+    stream capture).  Same kernels on the same data: every output bit-identical to side_overlap = 0 — also back to back,
+    where a missing join or a scratch buffer released before the side stream is done would show as a changed descriptor."""
+    model, _ = product_model("S", False, 28)
+    xs = [torch.from_numpy(synthetic_frames(B, 240, 320, seed=70 + i)).to(DEV) for i in range(3)]
+    with torch.no_grad():
+        model(xs[0])
+        _set_opt(model, "side_overlap", 0)
+        ref = [{k: v.clone() for k, v in model(x).items()} for x in xs]
+        _set_opt(model, "side_overlap", 1)
+        for rep in range(4):
+            got = [{k: v.clone() for k, v in model(x).items()} for x in xs]      # back to back, no synchronisation in between
+            for r, g in zip(ref, got):
+                for k in r:
+                    assert torch.equal(r[k], g[k]), (rep, k)
+
+
 def _set_opt(model, key, value):
     eng = model._engine
     assert eng.lib.kp2d_set_option(eng.handle, key.encode(), value) == 0
