@@ -972,12 +972,7 @@ static int launch_ws_t(const ConvArgs& a0, const StemArgs& st, hipStream_t s) {
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   static PerDeviceOnce lds_once;
   if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel<S16OUT, STEM>))) return e;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    else (void)hipGetLastError();
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cu_count();
   const int grid = (int)(ntiles < cus ? ntiles : cus);
   hipLaunchKernelGGL((conv3x3_f16x3_ws_kernel<S16OUT, STEM>), dim3(grid), dim3(768),
                      WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (STEM ? 4 * 2 * ST_XPL : 0), s, a, st, (int)ntiles);

@@ -486,12 +486,7 @@ static bool s16_eligible(const ConvArgs& a) {
 // runs per XCD), 0: too few items for the form (automatic: at least three rounds, as conv3x3_wsm.hip) — shared by the launcher
 // and by the plan, which must know BEFORE it picks the activation layout whether the form will run
 static int s16_grid(long nitems, int lanes, int min_items, int grid_opt) {
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    else (void)hipGetLastError();
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cu_count();
   int cap = grid_opt > 0 ? grid_opt : cus / (lanes > 1 ? lanes : 1);
   if (cap > cus) cap = cus;
   cap &= ~7;

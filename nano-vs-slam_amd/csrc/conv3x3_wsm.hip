@@ -738,8 +738,7 @@ int launch_conv3x3_f16x3_wsm(const ConvArgs& a0, hipStream_t s, int n_item) {
   a.tiles_y = (Ht + M_TH - 1) / M_TH;
   const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
   const long nitems = ntiles * (a.npad / n_item);
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = device_cu_count();
   const int lanes = a.wsm_lanes > 1 ? a.wsm_lanes : 1;
   int cap = a.wsm_grid > 0 ? a.wsm_grid : (grid_env > 0 ? grid_env : cus / lanes);
   if (cap > cus) cap = cus;
@@ -774,9 +773,7 @@ bool conv3x3_wsm_would_run(int B, int H, int W, int groups, int lanes, int wsm_m
   static const long min_env = getenv("KP2D_WSM") ? atol(getenv("KP2D_WSM")) : -1;
   static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;
   if (wsm_min < 0 || (wsm_min == 0 && min_env == 0) || W < 32) return false;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  else (void)hipGetLastError();
+  const int cus = device_cu_count();
   int cap = grid_opt > 0 ? grid_opt : (grid_env > 0 ? grid_env : cus / (lanes > 1 ? lanes : 1));
   if (cap > cus) cap = cus;
   cap &= ~7;

@@ -17,6 +17,20 @@ inline int lds_opt_in(PerDeviceOnce& once, const void* fn) {
   });
 }
 
+// Compute units of the CURRENT device, queried once per device (the persistent kernels size their grids by it at every
+// launch; all visible devices of a node are the same part, but the answer is kept per device anyway).
+inline int device_cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 16 && cached[dev] > 0) return cached[dev];
+  int n = 256;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
+  if (n <= 0) n = 256;
+  if (dev >= 0 && dev < 16) cached[dev] = n;
+  return n;
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool changed = false;

@@ -316,12 +316,7 @@ int launch_mff_tail(const MffTailArgs& a, hipStream_t s) {
   if ((long)a.H * a.W * MF_CH * 4 >= 0x7ffffff0L) return -1602;
   static PerDeviceOnce lds_once;
   if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&mff_tail_kernel))) return e;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    else (void)hipGetLastError();
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cu_count();
   const int tiles_x = (a.W + MF_T - 1) / MF_T, tiles_y = (a.H + MF_T - 1) / MF_T;
   const long ntiles = (long)tiles_x * tiles_y * a.B;
   if (ntiles >= (1L << 30)) return -1602;
