@@ -263,6 +263,12 @@ int kp2d_set_chunk_frames(kp2d_model* m, int frames);
  *                    results differ from every other tile form in the last bits — which is why it is opt-in: with it
  *                    off, outputs are bit-identical whatever the batch size, lane count or tile form
  *                    ("conv3x3_f16x3<wsm>t" in the profile).
+ *   "s16_all"        1 (default): big grids keep every tensor the warp-specialised 3x3 layers read as the fp16 halves of the
+ *                    split (LDS-DMA staging, conv3x3_wsm.hip; bit-identical); 0: only inside the backbone's 32-channel stage.
+ *   "side_overlap"   1 (default): a plain single-frame forward runs NetVLAD on a model-owned side stream beside the
+ *                    segmentation head (never under stream capture; the stream is created on first use); 0: in line — and
+ *                    the stream is destroyed (a process that keeps several streams busy wants the hardware queue back).
+ *   "stem_fusion", "s16_min_items", "multi_launch", "mff_fused": README.md's table of knobs.
  * Unknown keys return KP2D_ERR_ARG.  kp2d_profile_get reports the tile form each conv launch took behind its kernel
  * family ("conv3x3_f16x3<wsm>", "conv3x3_f16x3<2,1,16>", ...). */
 int kp2d_set_option(kp2d_model* m, const char* key, long value);
