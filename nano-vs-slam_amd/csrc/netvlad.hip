@@ -316,18 +316,29 @@ __global__ __launch_bounds__(256) void netvlad_partial_mfma_kernel(const VladArg
       for (int r = 0; r < 16; ++r) s_a[(pt1 * 32 + i) * AP + kt1 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = d[r];
     }
     __syncthreads();
-    {  // softmax over clusters: this thread owns clusters [q4*kq, (q4+1)*kq) of pixel p4
+    {  // softmax over clusters: this thread owns clusters [q4*kq, (q4+1)*kq) of pixel p4 — read once into registers,
+       // written once (the three passes over LDS of the first form were a third of the kernel's vector instructions)
       float* row = &s_a[p4 * AP + q4 * kq];
+      constexpr int KQ = 8 * KT;                       // kq <= KPAD / 4
+      float lv[KQ];
       float mx = -INFINITY;
-      for (int j = 0; j < kq; ++j) mx = fmaxf(mx, row[j]);
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) { lv[j] = j < kq ? row[j] : -INFINITY; mx = fmaxf(mx, lv[j]); }
       mx = fmaxf(mx, __shfl_xor(mx, 1));
       mx = fmaxf(mx, __shfl_xor(mx, 2));
       float se = 0.f;
-      for (int j = 0; j < kq; ++j) { const float e = expf(row[j] - mx); row[j] = e; se += e; }
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        // (the split-fp16 mode takes the hardware exponential, exp(x) = 2^(x log2 e): its logits are split products already)
+        lv[j] = SPLIT ? __builtin_amdgcn_exp2f((lv[j] - mx) * 1.44269504088896340736f) : expf(lv[j] - mx);
+        se += lv[j];                                   // (clusters past kq: exp(-inf) = 0)
+      }
       se += __shfl_xor(se, 1);
       se += __shfl_xor(se, 2);
       const float rs = (p4 < np) ? 1.f / se : 0.f;     // pixels past the slab contribute nothing
-      for (int j = 0; j < kq; ++j) row[j] *= rs;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j)
+        if (j < kq) row[j] = lv[j] * rs;
     }
     __syncthreads();
     if (has2) {   // step 2: V block (rows k, cols c), contraction over the tile's 64 pixels
