@@ -185,8 +185,9 @@ class FrameStream:
         self.copy_stream = torch.cuda.Stream(self.dev)
         # one compute stream per slot (KP2D_FS_SHARED_STREAM=1: the single shared stream of the first version, for A/B)
         shared = os.environ.get("KP2D_FS_SHARED_STREAM", "0") == "1"
-        one = torch.cuda.Stream(self.dev)
-        self.compute_streams = [one if shared else (one if s == 0 else torch.cuda.Stream(self.dev)) for s in range(self.slots)]
+        fs_prio = int(os.environ.get("KP2D_FS_PRIORITY", "0"))      # (A/B knob: -1 = high-priority slot streams)
+        one = torch.cuda.Stream(self.dev, priority=fs_prio)
+        self.compute_streams = [one if shared else (one if s == 0 else torch.cuda.Stream(self.dev, priority=fs_prio)) for s in range(self.slots)]
         self.compute_stream = self.compute_streams[0]
         self._slot_ws = [None] * self.slots        # per-slot engine workspace (the engine caches ONE otherwise)
         self.pin_in = [torch.empty(1, Hs, Ws, 3, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
@@ -453,7 +454,12 @@ class BatchStream:
             raise RuntimeError("BatchStream needs a HIP device (there is no CPU path)")
         self.dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
         self.net, self.slots, self.top_k, self.thr, self.select = net, max(1, int(slots)), top_k, nn_thresh, select
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.slots)]
+        # High-priority streams: the runtime keeps a separate pool of hardware queues per priority, so the slots' streams do
+        # not share queues with the process's other (normal-priority) streams — which queue a normal stream lands on depends
+        # on what the process created before (64 frames of 120 x 160: 62.4k frames/s or 77k by that accident alone; 76.2k
+        # every time this way; 240 x 320 batches: no difference; profiles/r5_hw_queues.txt).  KP2D_BS_PRIORITY=0: normal.
+        prio = int(os.environ.get("KP2D_BS_PRIORITY", "-1"))
+        self.streams = [torch.cuda.Stream(self.dev, priority=prio) for _ in range(self.slots)]
         self.events = [torch.cuda.Event() for _ in range(self.slots)]
         self._ws = [None] * self.slots
         self._res = [None] * self.slots
