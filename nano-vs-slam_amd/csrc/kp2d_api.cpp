@@ -1589,7 +1589,10 @@ static int forward_impl(kp2d_model* m, const float* x, const uint8_t* frames, in
   if (nl > 1) {
     while ((int)m->lane_streams.size() < nl - 1) {
       hipStream_t st; hipEvent_t ev;
-      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      // (KP2D_LANE_PRIORITY=-1: lane streams from the high-priority pool of hardware queues — an A/B knob, profiles/r5_hw_queues.txt)
+      static const int lane_prio = getenv("KP2D_LANE_PRIORITY") ? atoi(getenv("KP2D_LANE_PRIORITY")) : 0;
+      if (lane_prio != 0) HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lane_prio));
+      else HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       m->lane_streams.push_back(st); m->lane_events.push_back(ev);
     }
