@@ -27,8 +27,10 @@ step "sweep"
 : > "$OUT/sweep.jsonl"
 sweep() { timeout -k 10 300 python3 bench.py --no-cpu-baseline "$@" 2>"$(errf)" | tail -1 >> "$OUT/sweep.jsonl"; tail -1 "$OUT/sweep.jsonl" | cut -c60-100; }
 sweep --height 120 --width 160
+sweep --height 120 --width 160 --in-flight 4      # (short steps: four in flight, profiles/r5_hw_queues.txt)
 sweep
 sweep --batch 32
+sweep --batch 32 --in-flight 4
 sweep --height 480 --width 640 --batch 32
 sweep --config S_A --v3 --n-classes 19 --height 480 --width 640 --batch 32
 sweep --config S_A --v3
