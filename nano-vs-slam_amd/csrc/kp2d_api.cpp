@@ -1031,7 +1031,13 @@ void build(Plan& P, const FwdOut& o, uint32_t flags) {
   const int Hc = H >> g.downsample, Wc = W >> g.downsample;      // the cell grid (backbone output)
   const bool small_grid = (long)((Hc + 15) / 16) * ((Wc + 15) / 16) * P.B < 256;
   static const bool merge_always = getenv("KP2D_MERGE_HEADS") && getenv("KP2D_MERGE_HEADS")[0] == '2';
-  const bool big_wsm = m->precision == KP2D_PREC_F16X3 && !v3 && m->wsm_min >= 0 && (long)Hc * Wc >= 60 * 80;
+  // (round 5: 30 x 40 head maps too once the merged layer — five times the work items of one head's — runs on the
+  // warp-specialised form: 64 frames of 120 x 160: five launches of 0.031 ms -> one of 0.102, +0.5 ... +2 % end to end)
+  const int merged_groups = m->conv_index.count("heads.first") ? (m->convs[m->conv_index.at("heads.first")].npad / 64) : 0;
+  const bool big_wsm = m->precision == KP2D_PREC_F16X3 && !v3 && m->wsm_min >= 0 &&
+                       ((long)Hc * Wc >= 60 * 80 ||
+                        ((long)Hc * Wc >= 30 * 40 && merged_groups >= 2 &&
+                         conv3x3_wsm_would_run(B, Hc, Wc, merged_groups, P.nlanes, m->wsm_min, m->wsm_grid, 2)));
   const bool merged = merge_env && (small_grid || merge_always || big_wsm) && !only_enc && m->conv_index.count("heads.first");
   // Big grids of the plain V2 S configuration: S16P is the layout of EVERY tensor a split-fp16 3x3 layer of the warp-specialised
   // form reads — conv3b's two outputs, conv4a / 4b, the merged first layer's desc / seg / vlad slices, both pixel-shuffled
