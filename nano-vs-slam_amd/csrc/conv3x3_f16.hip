@@ -973,7 +973,9 @@ static int launch_ws_t(const ConvArgs& a0, const StemArgs& st, hipStream_t s) {
   static PerDeviceOnce lds_once;
   if (int e = lds_opt_in(lds_once, reinterpret_cast<const void*>(&conv3x3_f16x3_ws_kernel<S16OUT, STEM>))) return e;
   const int cus = device_cu_count();
-  const int grid = (int)(ntiles < cus ? ntiles : cus);
+  static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;      // (A/B knob: most workgroups of a persistent launch)
+  const int cap = grid_env > 0 && grid_env < cus ? grid_env : cus;
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
   hipLaunchKernelGGL((conv3x3_f16x3_ws_kernel<S16OUT, STEM>), dim3(grid), dim3(768),
                      WS_LDS + (S16OUT ? 8 * WS_BLK : 0) + (STEM ? 4 * 2 * ST_XPL : 0), s, a, st, (int)ntiles);
   return (int)hipGetLastError();

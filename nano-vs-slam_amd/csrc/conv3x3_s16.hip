@@ -487,7 +487,8 @@ static bool s16_eligible(const ConvArgs& a) {
 // and by the plan, which must know BEFORE it picks the activation layout whether the form will run
 static int s16_grid(long nitems, int lanes, int min_items, int grid_opt) {
   const int cus = device_cu_count();
-  int cap = grid_opt > 0 ? grid_opt : cus / (lanes > 1 ? lanes : 1);
+  static const int grid_env = getenv("KP2D_WSM_GRID") ? atoi(getenv("KP2D_WSM_GRID")) : 0;      // (the same knob as conv3x3_wsm.hip)
+  int cap = grid_opt > 0 ? grid_opt : (grid_env > 0 ? grid_env : cus / (lanes > 1 ? lanes : 1));
   if (cap > cus) cap = cus;
   cap &= ~7;
   if (cap < 8) return 0;
