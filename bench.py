@@ -49,8 +49,11 @@ LAYER_BOUNDARY_MB = {(240, 320): 123.86, (120, 160): 30.96, (480, 640): 495.44} 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 50 timed steps (0.13 s at 64 frames of 240x320) — with two steps in flight the first and the last step of the
+    # timed region run alone (pipeline fill and drain between the two synchronisations), which at 20 steps read 1.2 % below
+    # the rate sustained over 1000 (profiles/r5_box_variance.txt); 10 warm-up steps
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="frames per step over ALL ranks, split into contiguous shards (BASELINE cfg 3: 256 over 8 GPUs "
