@@ -395,6 +395,7 @@ __global__ __launch_bounds__(M_THREADS, 3) void conv3x3_f16x3_wsm_kernel(const C
   auto multiply = [&](int sb) {                      // sb: byte offset of the step's stage
 #pragma unroll
     for (int slot = 0; slot < 9; slot += 2) {
+      if (KP2D_DBG_ON(4) && slot >= 6) continue;      // (timing ablation: 9 of the 14 MFMAs per tile and chunk — what Winograd F(2,3) along rows would leave)
       const int tp = m_slot_tap(slot);
       const bool single = slot == 8;
       const bool dy = slot == 4;
